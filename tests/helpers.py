@@ -1,0 +1,60 @@
+"""Shared helpers for the parity tests (oracle side lives under oracle/, test-only)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from multimodal_transformer_amd.config import make_hyperparams
+from multimodal_transformer_amd.synthetic import make_batch
+from multimodal_transformer_amd.weights import apply_recipe
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TINY_TR = {"nlayers": 2, "nhead": 2, "in_dim": 32, "fdim": 64, "output_size": 32}
+MODES = ("basic", "map_cnn", "lane_cnn")
+
+
+def load_golden(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    with open(os.path.join(GOLDEN, tag + ".json")) as f:
+        meta = json.load(f)
+    return z, meta
+
+
+def hp_for(mode, tiny):
+    if tiny:
+        return make_hyperparams(mode, history=4, horizon=3, transformer=TINY_TR), 4, 3
+    return make_hyperparams(mode, history=8, horizon=12), 128, 12
+
+
+def batch_for(mode, tiny, B=None):
+    hp, b, ph = hp_for(mode, tiny)
+    b = B or b
+    return make_batch(b, history=hp["maximum_history_length"], horizon=ph, seed=1,
+                      with_map=(mode in ("map_cnn", "map_vit")), with_lanes=(mode == "lane_cnn"))
+
+
+def load_tiny_weights(model_dict, z):
+    """Copy the committed tiny-config weights ('w::<registrar key>.<param>') into a ModuleDict."""
+    with torch.no_grad():
+        for name, mod in model_dict.items():
+            for pn, t in mod.state_dict().items():
+                if pn.endswith("pos_encoder.pe"):
+                    continue
+                t.copy_(torch.from_numpy(z["w::" + f"{name}.{pn}"]))
+
+
+def set_weights(model_dict, tiny, z):
+    if tiny:
+        load_tiny_weights(model_dict, z)
+    else:
+        apply_recipe(model_dict, seed=0)
+
+
+def rel_err(a, b, floor=None):
+    """max |a-b| / max(|b|, floor) with floor defaulting to the RMS of b (per-output relative error)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if floor is None:
+        floor = float(np.sqrt(np.mean(b * b))) + 1e-30
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))

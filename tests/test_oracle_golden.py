@@ -1,0 +1,66 @@
+"""The oracle (oracle/reference_form.py) pinned against vectors produced by the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import MODES, batch_for, hp_for, load_golden, rel_err, set_weights
+from multimodal_transformer_amd.weights import checksum
+from oracle import reference_form as rf
+
+TOL = 1e-4   # north_star: per-output relative error <= 1e-4; ADE/FDE within 1e-3 m
+
+
+def _tensors(batch):
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    return t["x"], t["x_st"], t["y"], t["y_st"], t.get("lanes"), t.get("map")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("tiny", [True, False])
+def test_reference_form_matches_reference(mode, tiny):
+    torch.set_num_threads(8)
+    z, meta = load_golden(("tiny_" if tiny else "full_") + mode)
+    hp, B, ph = hp_for(mode, tiny)
+    model = rf.ReferenceFormModel(hp)
+    set_weights(model.m, tiny, z)
+    cs = checksum(model.m)
+    for k, v in meta["weights_checksum"].items():
+        assert cs[k]["numel"] == v["numel"]
+        assert abs(cs[k]["sum"] - v["sum"]) <= 1e-6 * max(1.0, v["abs_sum"])
+    x, x_st, y, y_st, lanes, maps = _tensors(batch_for(mode, tiny))
+    model.m.eval()
+    with torch.no_grad():
+        hist, lane = model.predict(x, x_st, lanes, maps, ph)
+        ev = model.eval_loss(x, x_st, y, y_st, lanes, maps, ph)
+    pred = lane if mode == "lane_cnn" else hist
+    node = x[:, -1, 0:2].numpy()
+    node = node[:, None, None, :] if mode == "lane_cnn" else node[:, None, :]
+    # compare in standardised units (the kernel's native output) and in metres
+    assert rel_err((pred.numpy() - node) / 80.0, (z["predict"] - node) / 80.0) <= TOL
+    ade, fde = rf.ade_fde(pred, y)
+    assert np.max(np.abs(ade.numpy() - z["ade"])) <= 1e-3
+    assert np.max(np.abs(fde.numpy() - z["fde"])) <= 1e-3
+    assert abs(float(ev) - float(z["eval_loss"])) <= TOL * abs(float(z["eval_loss"]))
+    if mode == "lane_cnn":
+        # quirk pin: lanes 1 and 2 are decoded with lane 0's feature (mgcvae.py:404)
+        assert np.array_equal(z["predict"][:, 0], z["predict"][:, 1])
+        assert np.array_equal(z["predict"][:, 0], z["predict"][:, 2])
+    # training loss with dropout off (modules in train mode, all p = 0)
+    hp["map_encoder"]["cnn_param"]["dropout"] = 0.0
+    model.m.train()
+    for m in model.m.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    loss = model.train_loss(x, x_st, y, y_st, lanes, maps, ph, train=True)
+    assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
+    if tiny:
+        loss.backward()
+        for name, mod in model.m.items():
+            for pn, p in mod.named_parameters():
+                key = "grad::" + f"{name}.{pn}"
+                if key in z.files:
+                    assert rel_err(p.grad.numpy(), z[key]) <= 1e-3, key
+                else:
+                    assert p.grad is None, key
