@@ -1,0 +1,153 @@
+/*
+ * mmt_amd.h -- C ABI of libmmt_amd.so: the MI355X (gfx950) hot path of
+ * gnsJhenJie/Multimodal_Transformer (Transformer/model + Transformer/nn_component).
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; its plugin
+ * interface is the string-keyed module registry (model/model_registrar.py:22-37)
+ * whose entries' forward() methods are what each entry point below replaces.
+ * All pointers are DEVICE pointers to contiguous fp32 (unless said otherwise),
+ * `stream` is a hipStream_t passed as void*, sizes are element counts.
+ * Every function returns 0 on success or a negative MMT_E* code; the message is
+ * available from mmt_last_error().  Nothing here allocates device memory: the
+ * caller brings outputs and a workspace (size from the *_workspace_floats calls).
+ *
+ * Weight layout: every nn.Linear weight W[N][K] used by a kernel is first
+ * re-laid-out once by mmt_pack_linear into "MFMA streaming order"
+ *   packed[slab = n/16][chunk = k/16][lane = 16*q + j][e]  = W[16*slab + j][16*chunk + 4*q + e]
+ * (N, K zero-padded to multiples of 16) so that one wave64 `global_load_dwordx4`
+ * reads 1 KiB of contiguous weights that feed four v_mfma_f32_16x16x4_f32.
+ * Biases / LayerNorm vectors stay plain fp32 arrays padded to a multiple of 16.
+ */
+#ifndef MMT_AMD_H
+#define MMT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMT_MAX_LAYERS 8
+#define MMT_MAX_MLP_HIDDEN 3
+#define MMT_MAX_CONV 4
+
+#define MMT_OK 0
+#define MMT_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MMT_ELAUNCH (-2)  /* HIP launch or runtime error     */
+
+/* one packed nn.Linear: y = x W^T + b  (b may be NULL = no bias) */
+typedef struct {
+  const float *w;   /* packed, mmt_packed_linear_floats(N,K) floats */
+  const float *b;   /* N padded to 16, or NULL                      */
+  int32_t n, k;     /* logical out / in features                    */
+} mmt_linear;
+
+typedef struct {
+  const float *g, *b;   /* LayerNorm weight / bias (eps 1e-5) */
+} mmt_norm;
+
+/* nn.TransformerEncoderLayer (post-norm, ReLU) -- Transformer_model.py:28-30 */
+typedef struct {
+  mmt_linear qkv, out, ff1, ff2;
+  mmt_norm ln1, ln2;
+} mmt_enc_layer;
+
+/* Encoder: Transformer_model.py:11-59 */
+typedef struct {
+  int32_t d_model, nhead, d_ff, nlayers, n_in;
+  mmt_linear input_fc;
+  const float *pe;            /* pos_encoder.pe buffer, row stride d_model */
+  mmt_enc_layer layer[MMT_MAX_LAYERS];
+} mmt_encoder;
+
+/* nn.TransformerDecoderLayer (post-norm, ReLU) -- Transformer_model.py:77-79 */
+typedef struct {
+  mmt_linear qkv, out;        /* self attention                                   */
+  mmt_linear cq, ckv, cout;   /* cross attention: q (rows 0..d), kv (rows d..3d)   */
+  mmt_linear ff1, ff2;
+  mmt_norm ln1, ln2, ln3;
+} mmt_dec_layer;
+
+/* Mlp (MLP.py:6-30), regression form: n_hidden x (Linear, LayerNorm, ReLU) + Linear */
+typedef struct {
+  int32_t n_hidden;
+  mmt_linear hidden[MMT_MAX_MLP_HIDDEN];
+  mmt_norm hidden_ln[MMT_MAX_MLP_HIDDEN];
+  mmt_linear out;
+} mmt_mlp;
+
+/* Trajectory_Decoder + decoder/MLP head (+ optional fusions) -- Transformer_model.py:155-199,
+ * mgcvae.py:375-449 */
+typedef struct {
+  int32_t d_model, nhead, d_ff, nlayers, n_in, n_out;
+  mmt_linear input_fc, output_fc;
+  const float *pe;
+  mmt_dec_layer layer[MMT_MAX_LAYERS];
+  mmt_mlp head;               /* VEHICLE/decoder/MLP                                    */
+  int32_t has_map_fusion;     /* VEHICLE/fusion/hist_map on cat[h, map_feat]            */
+  mmt_mlp map_fusion;
+  int32_t has_mem_fusion;     /* VEHICLE/fusion/lane_hist (or mix_fc) on cat[memory, f] */
+  mmt_mlp mem_fusion;
+} mmt_decoder;
+
+/* CNNMapEncoder: map_encoder.py:6-36 (conv weights plain [Cout][Cin][k][k]) */
+typedef struct {
+  int32_t nconv, in_ch, in_h, in_w;
+  int32_t out_ch[MMT_MAX_CONV], ksize[MMT_MAX_CONV], stride[MMT_MAX_CONV];
+  const float *conv_w[MMT_MAX_CONV], *conv_b[MMT_MAX_CONV];
+  const float *fc_w, *fc_b;   /* plain row-major [n_out][flat] */
+  int32_t n_out;
+  int32_t input_affine;       /* 1: the kernel applies map*2-1 (mgcvae.py:290) while reading the raster */
+} mmt_cnn;
+
+/* Lane_Encoder: Lane_encoder.py:7-33 (Conv1d + leaky_relu + Linear) */
+typedef struct {
+  int32_t in_ch, out_ch, ksize, stride, n_samples, n_out;
+  const float *conv_w, *conv_b, *fc_w, *fc_b;   /* plain layouts */
+} mmt_lane;
+
+const char *mmt_last_error(void);
+int mmt_version(void);
+
+/* ---- weight re-layout ------------------------------------------------------------------- */
+size_t mmt_packed_linear_floats(int n, int k);
+/* W row-major [n][ldw]; columns [col0, col0+k) are packed (lets callers split in_proj / cat inputs) */
+int mmt_pack_linear(const float *w, int n, int k, int ldw, int col0, float *dst, void *stream);
+
+/* ---- Encoder.forward  (Transformer_model.py:45-59; masks of model_utils.py:141-151 built in) --
+ * x_st (B,T,n_in) may hold NaN padding; memory (B,T,d) out; pad_mask (B,T) uint8 out (may be NULL). */
+int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory,
+                        uint8_t *pad_mask, void *stream);
+
+/* ---- autoregressive decode  (mgcvae.py:375-449 at_dec, basic/map branch, KV-cached) -------------
+ * memory (B,T,d); pad_mask (B,T) uint8 or NULL; start_pos (B,n_in) standardised; map_feat (B,m) or NULL;
+ * mem_feat (B,mf) or NULL (lane feature repeated over T, mgcvae.py:404-407);
+ * pred_st (B,ph,n_in) standardised positions out; h_out (B,ph,n_out) or NULL;
+ * tgt: NULL = feed predictions back (at_dec); else (B,ph,n_in) teacher-forced tokens
+ *      (Trajectory_Decoder.forward, Transformer_model.py:168-199; h_out is then the result).
+ * workspace: mmt_decoder_workspace_floats(...) floats. */
+size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph);
+int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
+                        const float *start_pos, const float *map_feat, int map_dim,
+                        const float *mem_feat, int mem_feat_dim, const float *tgt, int B, int T, int ph,
+                        float *pred_st, float *h_out, float *workspace, void *stream);
+
+/* ---- CNNMapEncoder.forward on map*2-1 (map_encoder.py:31-36, mgcvae.py:288-290) ------------------ */
+size_t mmt_cnn_workspace_floats(const mmt_cnn *cnn, int B);
+int mmt_cnn_forward(const mmt_cnn *cnn, const float *maps, int B, float *out, float *workspace, void *stream);
+
+/* ---- Lane_Encoder.forward on the raw (B*L, 2, S) view (Lane_encoder.py:29-33, mgcvae.py:301-306) -- */
+int mmt_lane_forward(const mmt_lane *lane, const float *lanes, int n_rows, float *out, void *stream);
+
+/* ---- un-standardise + ADE/FDE + L2 loss (mgcvae.py:614-620,708-715,772; evaluation.py:10-19) -------
+ * pred_st (B,ph,2); node_pos (B,2); pred_m (B,ph,2) out = pred_st*80 + node_pos (may be NULL);
+ * gt (B,ph,2) in the units of `metric_in_metres` (1: metres vs pred_m, 0: standardised vs pred_st)
+ * or NULL; ade/fde (B) out or NULL; loss_sum (1) accumulates sum_b mean_t ||.||2 (caller zeroes). */
+int mmt_finalize(const float *pred_st, const float *node_pos, const float *gt, int metric_in_metres,
+                 int B, int ph, float *pred_m, float *ade, float *fde, float *loss_sum, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMT_AMD_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libmmt_amd.so (declarations mirror include/mmt_amd.h one to one).
+
+There is no fallback: if the shared library is missing or a kernel is asked to run on
+anything but HIP device memory, the call raises.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C multimodal_transformer_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MMT_MAX_LAYERS = 8
+MMT_MAX_MLP_HIDDEN = 3
+MMT_MAX_CONV = 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmt_amd.so")
+
+fptr = C.c_void_p
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", fptr), ("b", fptr), ("n", C.c_int32), ("k", C.c_int32)]
+
+
+class Norm(C.Structure):
+    _fields_ = [("g", fptr), ("b", fptr)]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [("qkv", Linear), ("out", Linear), ("ff1", Linear), ("ff2", Linear), ("ln1", Norm), ("ln2", Norm)]
+
+
+class Encoder(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("nhead", C.c_int32), ("d_ff", C.c_int32), ("nlayers", C.c_int32),
+                ("n_in", C.c_int32), ("input_fc", Linear), ("pe", fptr), ("layer", EncLayer * MMT_MAX_LAYERS)]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [("qkv", Linear), ("out", Linear), ("cq", Linear), ("ckv", Linear), ("cout", Linear),
+                ("ff1", Linear), ("ff2", Linear), ("ln1", Norm), ("ln2", Norm), ("ln3", Norm)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("n_hidden", C.c_int32), ("hidden", Linear * MMT_MAX_MLP_HIDDEN),
+                ("hidden_ln", Norm * MMT_MAX_MLP_HIDDEN), ("out", Linear)]
+
+
+class Decoder(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("nhead", C.c_int32), ("d_ff", C.c_int32), ("nlayers", C.c_int32),
+                ("n_in", C.c_int32), ("n_out", C.c_int32), ("input_fc", Linear), ("output_fc", Linear), ("pe", fptr),
+                ("layer", DecLayer * MMT_MAX_LAYERS), ("head", Mlp), ("has_map_fusion", C.c_int32),
+                ("map_fusion", Mlp), ("has_mem_fusion", C.c_int32), ("mem_fusion", Mlp)]
+
+
+class Cnn(C.Structure):
+    _fields_ = [("nconv", C.c_int32), ("in_ch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("out_ch", C.c_int32 * MMT_MAX_CONV), ("ksize", C.c_int32 * MMT_MAX_CONV),
+                ("stride", C.c_int32 * MMT_MAX_CONV), ("conv_w", fptr * MMT_MAX_CONV), ("conv_b", fptr * MMT_MAX_CONV),
+                ("fc_w", fptr), ("fc_b", fptr), ("n_out", C.c_int32), ("input_affine", C.c_int32)]
+
+
+class Lane(C.Structure):
+    _fields_ = [("in_ch", C.c_int32), ("out_ch", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
+                ("n_samples", C.c_int32), ("n_out", C.c_int32), ("conv_w", fptr), ("conv_b", fptr), ("fc_w", fptr),
+                ("fc_b", fptr)]
+
+
+# symbol -> (restype, argtypes); tests check that the library exports exactly these
+SIGNATURES = {
+    "mmt_last_error": (C.c_char_p, []),
+    "mmt_version": (C.c_int, []),
+    "mmt_packed_linear_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "mmt_pack_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "mmt_encoder_forward": (C.c_int, [C.POINTER(Encoder), fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_decoder_workspace_floats": (C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
+    "mmt_decoder_forward": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
+                                      C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
+    "mmt_cnn_workspace_floats": (C.c_size_t, [C.POINTER(Cnn), C.c_int]),
+    "mmt_cnn_forward": (C.c_int, [C.POINTER(Cnn), fptr, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_lane_forward": (C.c_int, [C.POINTER(Lane), fptr, C.c_int, fptr, C.c_void_p]),
+    "mmt_finalize": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_void_p]),
+}
+
+_lib = None
+
+
+class MmtError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmmt_amd.so; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmtError(
+            f"{LIB_PATH} is not built: run `make -C multimodal_transformer_amd/csrc` (or __graft_entry__.build()). "
+            "This package has no CPU/PyTorch fallback for its kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mmt_last_error()
+        raise MmtError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

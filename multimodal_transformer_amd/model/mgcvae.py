@@ -1,0 +1,209 @@
+"""Model graph of the hot path behind the reference's ``MultimodalGenerativeCVAE`` interface
+(reference ``Transformer/model/mgcvae.py:21-773``): same constructor, same registry keys, same
+``predict`` / ``eval_loss`` / ``train_loss`` signatures and return values.
+
+What differs is *how* the graph runs: the reference launches ~1800 ATen kernels per predict
+(12 decoder passes over a growing target); here ``predict`` is four launches --
+encoder (K1), optional context encoder (K4/K5/K6), persistent KV-cached decoder with the head
+fused in (K2+K3), and un-standardise/metrics (K7).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import MmtError
+from ..nn_component import CNNMapEncoder, Encoder, Lane_Encoder, Mlp, Trajectory_Decoder, ViT
+from .model_utils import ModeKeys
+
+
+class MultimodalGenerativeCVAE(object):
+    def __init__(self, env, node_type, model_registrar, hyperparams, device, edge_types, log_writer=None):
+        self.hyperparams = hyperparams
+        self.env = env
+        self.node_type = node_type
+        self.model_registrar = model_registrar
+        self.log_writer = log_writer
+        self.device = device
+        self.edge_types = [e for e in edge_types if e[0] is node_type]
+        self.curr_iter = 0
+        self.node_modules = dict()
+        self.lane_dedup = True      # see at_dec_lane
+
+        self.min_hl = hyperparams["minimum_history_length"]
+        self.max_hl = hyperparams["maximum_history_length"]
+        self.ph = hyperparams["prediction_horizon"]
+        self.state = hyperparams["state"]
+        self.pred_state = hyperparams["pred_state"][node_type]
+        self.state_length = int(np.sum([len(v) for v in self.state[node_type].values()]))
+        if hyperparams["incl_robot_node"]:
+            self.robot_state_length = int(np.sum([len(v) for v in self.state[env.robot_type].values()]))
+        self.pred_state_length = int(np.sum([len(v) for v in self.pred_state.values()]))
+        self.create_submodule([])
+
+    # ------------------------------------------------------------------ registry plumbing
+    def set_curr_iter(self, curr_iter):
+        self.curr_iter = curr_iter
+
+    def add_submodule(self, name, model_if_absent):
+        self.node_modules[name] = self.model_registrar.get_model(name, model_if_absent)
+
+    def clear_submodules(self):
+        self.node_modules.clear()
+
+    def _m(self, suffix):
+        return self.node_modules[self.node_type + "/" + suffix]
+
+    def create_models(self):
+        """Same keys / constructor arguments as mgcvae.py:77-212."""
+        hp, nt = self.hyperparams, self.node_type
+        tr = hp["transformer"]
+        self.add_submodule(nt + "/node_history_encoder", Encoder(
+            ninp=self.state_length, nlayers=tr["nlayers"], nhead=tr["nhead"], in_dim=tr["in_dim"], fdim=tr["fdim"]))
+        if hp["lane_cnn_encoding"]:
+            le = hp["lane_encoder"][nt]
+            self.add_submodule(nt + "/lane_encoder", Lane_Encoder(
+                le["nlayers"], le["embedding_size"], le["map_channels"], le["output_size"], le["kernel_size"],
+                le["strides"]))
+            self.add_submodule(nt + "/fusion/lane_hist", Mlp(
+                in_channels=tr["in_dim"] + le["output_size"], output_size=tr["in_dim"],
+                layer_num=hp["fusion_hist_map_layer"], mode="regression"))
+            self.add_submodule(nt + "/Lane/MLP_Softmax", Mlp(
+                in_channels=le["output_size"] * 3, output_size=hp["max_lane_num"], layer_num=hp["mlp_layer"],
+                mode="classification"))
+        else:
+            map_out = None
+            if hp["map_vit_encoding"]:
+                vp = hp["map_encoder"]["vit_param"]
+                map_out = vp["output_size"]
+                self.add_submodule(nt + "/map_encoder", ViT(
+                    image_size=vp["image_size"], patch_size=vp["patch_size"], num_classes=vp["output_size"],
+                    dim=vp["dim"], depth=vp["deep"], heads=vp["heads"], mlp_dim=vp["mlp_dim"], dropout=vp["dropout"],
+                    emb_dropout=vp["emb_dropout"]))
+            elif hp["map_cnn_encoding"]:
+                cp = hp["map_encoder"]["cnn_param"]
+                map_out = cp["output_size"]
+                self.add_submodule(nt + "/map_encoder", CNNMapEncoder(
+                    cp["map_channels"], cp["hidden_channels"], cp["output_size"], cp["masks"], cp["strides"],
+                    cp["patch_size"]))
+            if map_out is not None:
+                self.add_submodule(nt + "/fusion/hist_map", Mlp(
+                    in_channels=tr["output_size"] + map_out, output_size=tr["output_size"],
+                    layer_num=hp["fusion_hist_map_layer"], mode="regression"))
+        self.add_submodule(nt + "/decoder/MLP", Mlp(
+            in_channels=tr["output_size"], output_size=self.pred_state_length, layer_num=hp["mlp_layer"],
+            mode="regression"))
+        self.add_submodule(nt + "/decoder/transformer_decoder", Trajectory_Decoder(
+            nlayers=tr["nlayers"], tgt_inp=self.pred_state_length,
+            lane_inp=hp["lane_encoder"]["VEHICLE"]["output_size"], in_dim=tr["in_dim"], nhead=tr["nhead"],
+            fdim=tr["fdim"], noutput=tr["output_size"]))
+
+    def create_submodule(self, edge_types):
+        self.clear_submodules()
+        self.create_models()
+        for module in self.node_modules.values():
+            module.to(self.device)
+
+    # ------------------------------------------------------------------ forward pieces
+    def obtain_encoded_tensors(self, mode, inputs, inputs_st, inputs_lane, map):
+        """mgcvae.py:231-308.  Returns the same 7-tuple; the causal mask slot is None because the kernels
+        rebuild it, the padding mask is the uint8 (B,T) tensor the encoder kernel derived."""
+        hp = self.hyperparams
+        memory, pad = self._m("node_history_encoder").forward_with_mask(inputs_st)
+        encoded_map = encoded_lane = None
+        if hp["map_cnn_encoding"] or hp["map_vit_encoding"]:
+            if mode == ModeKeys.TRAIN:
+                raise MmtError("training-mode dropout on the map feature is not implemented in the HIP path")
+            encoded_map = self._m("map_encoder").forward_raw(map)
+        elif hp["lane_cnn_encoding"]:
+            B = inputs.shape[0]
+            ln, sn = hp["max_lane_num"], hp["sample_num"]
+            emb = hp["lane_encoder"][self.node_type]["embedding_size"]
+            flat = inputs_lane.contiguous().view(B * ln, emb, sn)     # raw reinterpretation (mgcvae.py:301-302)
+            encoded_lane = self._m("lane_encoder")(flat).view(B, ln, -1)
+        return memory, None, pad, inputs_st[:, -1], inputs[:, -1, 0:2], encoded_lane, encoded_map
+
+    def at_dec(self, memory, memory_mask, memory_key_padding_mask, n_s_t0, lane_feature, map_feature,
+               prediction_horizon):
+        """mgcvae.py:375-449 as one persistent kernel launch per decode."""
+        hp = self.hyperparams
+        dec = self._m("decoder/transformer_decoder")
+        head = self._m("decoder/MLP")
+        start = n_s_t0[:, 0:self.pred_state_length].contiguous()
+        if hp["lane_cnn_encoding"]:
+            return None, self.at_dec_lane(dec, head, memory, memory_key_padding_mask, start, lane_feature,
+                                          prediction_horizon)
+        fusion = self._m("fusion/hist_map") if map_feature is not None else None
+        packed = dec.packed(head=head, map_fusion=fusion)
+        pred, _ = ops.decoder_forward(packed, memory, memory_key_padding_mask, start, prediction_horizon,
+                                      map_feat=map_feature)
+        return pred, []
+
+    def at_dec_lane(self, dec, head, memory, pad, start, lane_feature, ph):
+        """Lane branch (mgcvae.py:395-424).  The reference overwrites ``lane_feature`` inside its lane loop
+        (:404), so lanes 1 and 2 are decoded with lane 0's feature and -- dropout off -- are bit-identical to
+        lane 0.  ``lane_dedup`` (default) launches the decode once and returns the result three times;
+        setting it False launches one decode per lane, like the reference."""
+        packed = dec.packed(head=head, mem_fusion=self._m("fusion/lane_hist"))
+        feat0 = lane_feature[:, 0, :].contiguous()
+        n_lane = lane_feature.shape[-2]
+        if memory.shape[-2] < n_lane:
+            raise MmtError("lane decoding needs history length >= max_lane_num (the reference indexes the "
+                           "repeated lane tensor by lane number, mgcvae.py:404)")
+        outs = []
+        for i in range(n_lane):
+            if i == 0 or not self.lane_dedup:
+                pred, _ = ops.decoder_forward(packed, memory, pad, start, ph, mem_feat=feat0)
+            outs.append(pred)
+        return outs
+
+    # ------------------------------------------------------------------ public entry points
+    def predict(self, inputs, inputs_st, inputs_lane, lane_t_mask, map, prediction_horizon):
+        """mgcvae.py:720-773 -> (history_pred (B,ph,2) metres | None, lane_pred (B,3,ph,2) metres | None/[])."""
+        memory, _, pad, n0, node_pos, enc_lane, enc_map = self.obtain_encoded_tensors(
+            ModeKeys.EVAL, inputs, inputs_st, inputs_lane, map)
+        hist, lane = self.at_dec(memory, None, pad, n0, enc_lane, enc_map, prediction_horizon)
+        node_pos = node_pos.contiguous()
+        if self.hyperparams["lane_cnn_encoding"]:
+            m0 = ops.finalize(lane[0], node_pos)[0]
+            outs = [m0 if (self.lane_dedup or i == 0) else ops.finalize(lane[i], node_pos)[0]
+                    for i in range(len(lane))]
+            return None, torch.stack(outs, dim=1)
+        return ops.finalize(hist, node_pos)[0], lane
+
+    def _loss(self, inputs, inputs_st, inputs_lane, labels, labels_st, map, ph, metres, mode):
+        memory, _, pad, n0, node_pos, enc_lane, enc_map = self.obtain_encoded_tensors(
+            mode, inputs, inputs_st, inputs_lane, map)
+        hist, lane = self.at_dec(memory, None, pad, n0, enc_lane, enc_map, ph)
+        gt = (labels if metres else labels_st).contiguous()
+        node_pos = node_pos.contiguous()
+        B = inputs.shape[0]
+        if self.hyperparams["lane_cnn_encoding"]:
+            # per-lane mean L2, then min over lanes, then batch mean (mgcvae.py:603-612,620)
+            per = [ops.finalize(p, node_pos, gt, metres=metres, want_pred=False, want_metrics=True)[1] for p in
+                   (lane[:1] if self.lane_dedup else lane)]
+            per = per[0] if len(per) == 1 else torch.stack(per, dim=-1).min(dim=-1)[0]
+            loss = per.sum() / B
+        else:
+            loss = ops.finalize(hist, node_pos, gt, metres=metres, want_pred=False, want_loss=True)[3][0] / B
+        return loss
+
+    def eval_loss(self, node_type, inputs, inputs_st, inputs_lane, lane_label, lane_t_mask, labels, labels_st, map,
+                  prediction_horizon):
+        """mgcvae.py:629-718: mean over agents of the mean per-step L2 error in metres -> (loss, reg_loss)."""
+        loss = self._loss(inputs, inputs_st, inputs_lane, labels, labels_st, map, prediction_horizon, True,
+                          ModeKeys.EVAL)
+        return loss, loss
+
+    def train_loss(self, inputs, inputs_st, inputs_lane, lane_label, lane_t_mask, labels, labels_st, map,
+                   prediction_horizon):
+        """mgcvae.py:559-627, forward value only (standardised units, dropout off).  The backward pass / fused
+        AdamW of the training step are not in this round's kernels: the returned tensor carries no graph."""
+        if not self.hyperparams["autoregressive"]:
+            raise MmtError("teacher-forced training (non_at_dec) is not implemented; pass autoregressive=True")
+        loss = self._loss(inputs, inputs_st, inputs_lane, labels, labels_st, map, prediction_horizon, False,
+                          ModeKeys.EVAL)
+        if self.log_writer is not None:
+            self.log_writer.add_scalar("%s/%s" % (str(self.node_type), "loss"), loss, self.curr_iter)
+        return loss, loss

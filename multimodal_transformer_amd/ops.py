@@ -1,0 +1,410 @@
+"""Host-side operator layer: torch tensors in, HIP kernels (through the C ABI) out.
+
+Every function here validates its operands (device, dtype, contiguity, shapes) before the
+kernel is launched, launches on torch's current HIP stream and returns torch tensors that were
+allocated by the torch caching allocator.  There is deliberately no CPU / ATen implementation of
+any op in this file: a CPU tensor or a missing libmmt_amd.so raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MmtError
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, name, shape=None, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise MmtError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise MmtError(f"{name}: tensor is on {t.device}; the HIP kernels need device memory (no CPU fallback)")
+    if t.dtype != dtype:
+        raise MmtError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise MmtError(f"{name}: tensor must be contiguous")
+    if shape is not None:
+        if len(shape) != t.dim() or any(s is not None and s != ts for s, ts in zip(shape, t.shape)):
+            raise MmtError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _r16(v):
+    return (v + 15) & ~15
+
+
+class _Arena:
+    """One flat device buffer holding the packed weights of a module (keeps everything alive)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.plan = []        # (kind, args) recorded first, so the buffer is allocated once
+        self.size = 0
+        self.buf = None
+
+    def reserve(self, nfloats):
+        off = self.size
+        self.size += (nfloats + 63) & ~63          # 256-byte aligned pieces
+        return off
+
+    def alloc(self):
+        self.buf = torch.zeros(max(self.size, 64), dtype=torch.float32, device=self.device)
+
+    def addr(self, off):
+        return self.buf.data_ptr() + 4 * off
+
+
+class _Packer:
+    def __init__(self, device):
+        self.arena = _Arena(device)
+        self.jobs = []
+        self.lib = _lib.load()
+
+    def linear(self, w, b=None, col0=0, k=None, row0=0, n=None):
+        """Plan the packing of rows [row0,row0+n) / cols [col0,col0+k) of a (N,K) weight."""
+        _chk(w, "weight")
+        N, K = w.shape
+        n = N - row0 if n is None else n
+        k = K - col0 if k is None else k
+        woff = self.arena.reserve(self.lib.mmt_packed_linear_floats(n, k))
+        boff = self.arena.reserve(_r16(n)) if b is not None else None
+        L = _lib.Linear()
+        L.n, L.k = n, k
+        self.jobs.append(("lin", L, w, b, row0, col0, n, k, woff, boff))
+        return L
+
+    def norm(self, g, b):
+        goff = self.arena.reserve(_r16(g.numel()))
+        boff = self.arena.reserve(_r16(b.numel()))
+        Nn = _lib.Norm()
+        self.jobs.append(("norm", Nn, g, b, goff, boff))
+        return Nn
+
+    def plain(self, t):
+        off = self.arena.reserve(t.numel())
+        holder = [None]
+        self.jobs.append(("plain", holder, t, off))
+        return holder
+
+    def finish(self):
+        A = self.arena
+        A.alloc()
+        st = _stream()
+        for job in self.jobs:
+            if job[0] == "lin":
+                _, L, w, b, row0, col0, n, k, woff, boff = job
+                src = w.data_ptr() + 4 * row0 * w.shape[1]
+                _lib.check(self.lib.mmt_pack_linear(C.c_void_p(src), n, k, w.shape[1], col0, C.c_void_p(A.addr(woff)), st),
+                           "mmt_pack_linear")
+                L.w = A.addr(woff)
+                if b is not None:
+                    A.buf[boff:boff + n].copy_(b.detach().reshape(-1)[row0:row0 + n])
+                    L.b = A.addr(boff)
+                else:
+                    L.b = None
+            elif job[0] == "norm":
+                _, Nn, g, b, goff, boff = job
+                A.buf[goff:goff + g.numel()].copy_(g.detach().reshape(-1))
+                A.buf[boff:boff + b.numel()].copy_(b.detach().reshape(-1))
+                Nn.g, Nn.b = A.addr(goff), A.addr(boff)
+            else:
+                _, holder, t, off = job
+                A.buf[off:off + t.numel()].copy_(t.detach().reshape(-1))
+                holder[0] = A.addr(off)
+        return A
+
+
+def _copy_struct(dst, src):
+    C.memmove(C.byref(dst), C.byref(src), C.sizeof(src))
+
+
+def _mlp_desc(pk, sd, prefix):
+    """Mlp (MLP.py) regression form from state_dict names ``layer_seq.lmlp_i.{0,1}.*`` / ``layer_seq.out_mlp.*``."""
+    M = _lib.Mlp()
+    i = 0
+    pend = []
+    while f"{prefix}layer_seq.lmlp_{i}.0.weight" in sd:
+        if i >= _lib.MMT_MAX_MLP_HIDDEN:
+            raise MmtError(f"Mlp with more than {_lib.MMT_MAX_MLP_HIDDEN} hidden layers is not supported")
+        p = f"{prefix}layer_seq.lmlp_{i}."
+        pend.append((pk.linear(sd[p + "0.weight"], sd[p + "0.bias"]), pk.norm(sd[p + "1.weight"], sd[p + "1.bias"])))
+        i += 1
+    if f"{prefix}layer_seq.out_mlp.weight" not in sd:
+        raise MmtError("only regression-mode Mlp can run inside the decoder kernel")
+    out = pk.linear(sd[f"{prefix}layer_seq.out_mlp.weight"], sd[f"{prefix}layer_seq.out_mlp.bias"])
+    return M, pend, out
+
+
+def _fill_mlp(M, pend, out):
+    M.n_hidden = len(pend)
+    for i, (lin, nrm) in enumerate(pend):
+        _copy_struct(M.hidden[i], lin)
+        _copy_struct(M.hidden_ln[i], nrm)
+    _copy_struct(M.out, out)
+
+
+def _version_key(tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+class PackedEncoder:
+    """Device-side descriptor of an Encoder (Transformer_model.py:11-59) built from its state_dict."""
+
+    def __init__(self, sd: dict, nhead: int):
+        w_in = sd["input_fc.weight"]
+        dev = w_in.device
+        d, n_in = w_in.shape
+        pk = _Packer(dev)
+        E = _lib.Encoder()
+        E.d_model, E.nhead, E.n_in = d, nhead, n_in
+        lin_in = pk.linear(w_in, sd["input_fc.bias"])
+        pe = pk.plain(sd["pos_encoder.pe"][:64])     # T <= 32 rows are ever read
+        layers = []
+        L = 0
+        while f"transformer_encoder.layers.{L}.linear1.weight" in sd:
+            p = f"transformer_encoder.layers.{L}."
+            layers.append(dict(
+                qkv=pk.linear(sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]),
+                out=pk.linear(sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"]),
+                ff1=pk.linear(sd[p + "linear1.weight"], sd[p + "linear1.bias"]),
+                ff2=pk.linear(sd[p + "linear2.weight"], sd[p + "linear2.bias"]),
+                ln1=pk.norm(sd[p + "norm1.weight"], sd[p + "norm1.bias"]),
+                ln2=pk.norm(sd[p + "norm2.weight"], sd[p + "norm2.bias"])))
+            L += 1
+        if L == 0 or L > _lib.MMT_MAX_LAYERS:
+            raise MmtError(f"encoder with {L} layers is not supported (1..{_lib.MMT_MAX_LAYERS})")
+        E.nlayers = L
+        E.d_ff = sd["transformer_encoder.layers.0.linear1.weight"].shape[0]
+        self.arena = pk.finish()
+        _copy_struct(E.input_fc, lin_in)
+        E.pe = pe[0]
+        for i, lay in enumerate(layers):
+            for k, v in lay.items():
+                _copy_struct(getattr(E.layer[i], k), v)
+        self.desc = E
+        self.d_model = d
+        self.n_in = n_in
+
+
+class PackedDecoder:
+    """Trajectory_Decoder + head Mlp (+ optional map / memory fusion Mlps) descriptor."""
+
+    def __init__(self, sd: dict, nhead: int, head_sd: dict, map_fusion_sd: dict | None = None,
+                 mem_fusion_sd: dict | None = None, mem_fusion_is_mix_fc: bool = False):
+        w_in = sd["input_fc.weight"]
+        dev = w_in.device
+        d, n_in = w_in.shape
+        pk = _Packer(dev)
+        D = _lib.Decoder()
+        D.d_model, D.nhead, D.n_in = d, nhead, n_in
+        D.n_out = sd["output_fc.weight"].shape[0]
+        lin_in = pk.linear(w_in, sd["input_fc.bias"])
+        lin_out = pk.linear(sd["output_fc.weight"], sd["output_fc.bias"])
+        pe = pk.plain(sd["pos_encoder.pe"][:64])
+        layers = []
+        L = 0
+        while f"transformer_decoder.layers.{L}.linear1.weight" in sd:
+            p = f"transformer_decoder.layers.{L}."
+            cw, cb = sd[p + "multihead_attn.in_proj_weight"], sd[p + "multihead_attn.in_proj_bias"]
+            layers.append(dict(
+                qkv=pk.linear(sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"]),
+                out=pk.linear(sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"]),
+                cq=pk.linear(cw, cb, row0=0, n=d),
+                ckv=pk.linear(cw, cb, row0=d, n=2 * d),
+                cout=pk.linear(sd[p + "multihead_attn.out_proj.weight"], sd[p + "multihead_attn.out_proj.bias"]),
+                ff1=pk.linear(sd[p + "linear1.weight"], sd[p + "linear1.bias"]),
+                ff2=pk.linear(sd[p + "linear2.weight"], sd[p + "linear2.bias"]),
+                ln1=pk.norm(sd[p + "norm1.weight"], sd[p + "norm1.bias"]),
+                ln2=pk.norm(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
+                ln3=pk.norm(sd[p + "norm3.weight"], sd[p + "norm3.bias"])))
+            L += 1
+        if L == 0 or L > _lib.MMT_MAX_LAYERS:
+            raise MmtError(f"decoder with {L} layers is not supported (1..{_lib.MMT_MAX_LAYERS})")
+        D.nlayers = L
+        D.d_ff = sd["transformer_decoder.layers.0.linear1.weight"].shape[0]
+        head = _mlp_desc(pk, head_sd, "") if head_sd is not None else None
+        mapf = _mlp_desc(pk, map_fusion_sd, "") if map_fusion_sd is not None else None
+        memf = None
+        if mem_fusion_sd is not None:
+            if mem_fusion_is_mix_fc:   # Trajectory_Decoder.mix_fc is a bare Linear (Transformer_model.py:166,189-191)
+                memf = (_lib.Mlp(), [], pk.linear(mem_fusion_sd["weight"], mem_fusion_sd["bias"]))
+            else:
+                memf = _mlp_desc(pk, mem_fusion_sd, "")
+        self.arena = pk.finish()
+        _copy_struct(D.input_fc, lin_in)
+        _copy_struct(D.output_fc, lin_out)
+        D.pe = pe[0]
+        for i, lay in enumerate(layers):
+            for k, v in lay.items():
+                _copy_struct(getattr(D.layer[i], k), v)
+        if head is not None:
+            _fill_mlp(D.head, head[1], head[2])
+        D.has_map_fusion = int(mapf is not None)
+        if mapf is not None:
+            _fill_mlp(D.map_fusion, mapf[1], mapf[2])
+        D.has_mem_fusion = int(memf is not None)
+        if memf is not None:
+            _fill_mlp(D.mem_fusion, memf[1], memf[2])
+        self.has_head = head is not None
+        self.desc = D
+        self.d_model, self.n_in, self.n_out = d, n_in, D.n_out
+
+
+class PackedCnn:
+    """CNNMapEncoder (map_encoder.py:6-36) descriptor: plain conv / fc weights copied into one arena."""
+
+    def __init__(self, sd: dict, strides, in_hw):
+        pk = _Packer(sd["fc.weight"].device)
+        N = _lib.Cnn()
+        holders = []
+        i = 0
+        while f"convs.{i}.weight" in sd:
+            if i >= _lib.MMT_MAX_CONV:
+                raise MmtError(f"more than {_lib.MMT_MAX_CONV} conv layers are not supported")
+            w = sd[f"convs.{i}.weight"]
+            if w.shape[2] != w.shape[3]:
+                raise MmtError("only square conv kernels are supported")
+            N.out_ch[i], N.ksize[i], N.stride[i] = w.shape[0], w.shape[2], int(strides[i])
+            if i == 0:
+                N.in_ch = w.shape[1]
+            holders.append((pk.plain(w), pk.plain(sd[f"convs.{i}.bias"])))
+            i += 1
+        N.nconv = i
+        N.in_h, N.in_w = int(in_hw[0]), int(in_hw[1])
+        fw, fb = pk.plain(sd["fc.weight"]), pk.plain(sd["fc.bias"])
+        N.n_out = sd["fc.weight"].shape[0]
+        self.flat = sd["fc.weight"].shape[1]
+        self.arena = pk.finish()
+        for j, (hw, hb) in enumerate(holders):
+            N.conv_w[j], N.conv_b[j] = hw[0], hb[0]
+        N.fc_w, N.fc_b = fw[0], fb[0]
+        self.desc = N
+
+
+class PackedLane:
+    """Lane_Encoder (Lane_encoder.py:7-33) descriptor."""
+
+    def __init__(self, sd: dict, stride: int, n_samples: int):
+        pk = _Packer(sd["fc.weight"].device)
+        N = _lib.Lane()
+        w = sd["convs.0.weight"]
+        N.out_ch, N.in_ch, N.ksize = w.shape
+        N.stride, N.n_samples = int(stride), int(n_samples)
+        N.n_out = sd["fc.weight"].shape[0]
+        hs = [pk.plain(w), pk.plain(sd["convs.0.bias"]), pk.plain(sd["fc.weight"]), pk.plain(sd["fc.bias"])]
+        self.arena = pk.finish()
+        N.conv_w, N.conv_b, N.fc_w, N.fc_b = (h[0] for h in hs)
+        self.desc = N
+        width = (n_samples - N.ksize) // N.stride + 1
+        if N.out_ch * width != sd["fc.weight"].shape[1]:
+            raise MmtError("lane encoder: fc input size does not match conv output")
+
+
+# ------------------------------------------------------------------------------------------ ops
+def encoder_forward(enc: PackedEncoder, x_st: torch.Tensor, want_mask: bool = True):
+    """Encoder.forward incl. the causal / key-padding masks -> (memory (B,T,d), pad_mask (B,T) uint8)."""
+    _chk(x_st, "x_st", (None, None, enc.n_in))
+    B, T, _ = x_st.shape
+    if B == 0:
+        raise MmtError("x_st: empty batch")
+    memory = torch.empty(B, T, enc.d_model, dtype=torch.float32, device=x_st.device)
+    pad = torch.empty(B, T, dtype=torch.uint8, device=x_st.device) if want_mask else None
+    lib = _lib.load()
+    _lib.check(lib.mmt_encoder_forward(C.byref(enc.desc), _ptr(x_st), B, T, _ptr(memory), _ptr(pad), _stream()),
+               "mmt_encoder_forward")
+    return memory, pad
+
+
+_ws_cache = {}
+
+
+def _workspace(nfloats, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(int(nfloats * 1.25) + 1024, dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12, map_feat=None, mem_feat=None,
+                    tgt=None, want_h=False):
+    """Autoregressive (tgt=None) or teacher-forced decode.  Returns (pred_st (B,ph,n_in) | None, h (B,ph,n_out) | None)."""
+    _chk(memory, "memory", (None, None, dec.d_model))
+    B, T, _ = memory.shape
+    if pad_mask is not None:
+        _chk(pad_mask, "pad_mask", (B, T), torch.uint8)
+    if tgt is None:
+        _chk(start_pos, "start_pos", (B, dec.n_in))
+        if not dec.has_head:
+            raise MmtError("autoregressive decoding needs the decoder/MLP head")
+    else:
+        _chk(tgt, "tgt", (B, None, dec.n_in))
+        ph = tgt.shape[1]
+    md = mf = 0
+    if map_feat is not None:
+        _chk(map_feat, "map_feat", (B, None))
+        md = map_feat.shape[1]
+    if mem_feat is not None:
+        _chk(mem_feat, "mem_feat", (B, None))
+        mf = mem_feat.shape[1]
+    dev = memory.device
+    pred = torch.empty(B, ph, dec.n_in, dtype=torch.float32, device=dev) if tgt is None else None
+    h = torch.empty(B, ph, dec.n_out, dtype=torch.float32, device=dev) if (want_h or tgt is not None) else None
+    lib = _lib.load()
+    ws = _workspace(lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph), dev)
+    _lib.check(lib.mmt_decoder_forward(C.byref(dec.desc), _ptr(memory), _ptr(pad_mask), _ptr(start_pos), _ptr(map_feat),
+                                       md, _ptr(mem_feat), mf, _ptr(tgt), B, T, ph, _ptr(pred), _ptr(h), _ptr(ws),
+                                       _stream()), "mmt_decoder_forward")
+    return pred, h
+
+
+def cnn_forward(cnn: PackedCnn, maps: torch.Tensor, input_affine: bool = True):
+    """CNNMapEncoder.forward: maps (B,C,H,W) -> (B,n_out); input_affine applies map*2-1 inside the kernel."""
+    N = cnn.desc
+    N.input_affine = int(bool(input_affine))
+    _chk(maps, "map", (None, N.in_ch, N.in_h, N.in_w))
+    B = maps.shape[0]
+    out = torch.empty(B, N.n_out, dtype=torch.float32, device=maps.device)
+    lib = _lib.load()
+    _lib.check(lib.mmt_cnn_forward(C.byref(N), _ptr(maps), B, _ptr(out), None, _stream()), "mmt_cnn_forward")
+    return out
+
+
+def lane_forward(lane: PackedLane, lanes: torch.Tensor):
+    """Lane_Encoder.forward on rows of (in_ch*n_samples) floats: (R, in_ch, n_samples) -> (R, n_out)."""
+    N = lane.desc
+    _chk(lanes, "lanes", (None, N.in_ch, N.n_samples))
+    R = lanes.shape[0]
+    out = torch.empty(R, N.n_out, dtype=torch.float32, device=lanes.device)
+    lib = _lib.load()
+    _lib.check(lib.mmt_lane_forward(C.byref(N), _ptr(lanes), R, _ptr(out), _stream()), "mmt_lane_forward")
+    return out
+
+
+def finalize(pred_st, node_pos=None, gt=None, metres=True, want_pred=True, want_metrics=False, want_loss=False):
+    """pred_st*80+node_pos, ADE/FDE and the summed per-agent mean L2 in one pass over (B,ph,2)."""
+    _chk(pred_st, "pred_st", (None, None, 2))
+    B, ph, _ = pred_st.shape
+    dev = pred_st.device
+    if node_pos is not None:
+        _chk(node_pos, "node_pos", (B, 2))
+    if gt is not None:
+        _chk(gt, "gt", (B, ph, 2))
+    pred_m = torch.empty_like(pred_st) if want_pred else None
+    ade = torch.empty(B, dtype=torch.float32, device=dev) if want_metrics else None
+    fde = torch.empty(B, dtype=torch.float32, device=dev) if want_metrics else None
+    loss = torch.zeros(1, dtype=torch.float32, device=dev) if want_loss else None
+    lib = _lib.load()
+    _lib.check(lib.mmt_finalize(_ptr(pred_st), _ptr(node_pos), _ptr(gt), int(bool(metres)), B, ph, _ptr(pred_m), _ptr(ade),
+                                _ptr(fde), _ptr(loss), _stream()), "mmt_finalize")
+    return pred_m, ade, fde, loss

@@ -1,0 +1,211 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors generated from the
+reference and against the CPU oracle on seeded inputs.
+
+Tolerances (BASELINE.json north_star): per-output relative error <= 1e-4 on the kernel's native
+(standardised) outputs, ADE/FDE within 1e-3 m.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import MODES, TINY_TR, batch_for, hp_for, load_golden, rel_err, set_weights
+from multimodal_transformer_amd.config import make_hyperparams
+from multimodal_transformer_amd.synthetic import make_batch
+from multimodal_transformer_amd.weights import apply_recipe
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+class _Env:
+    robot_type = None
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _model(hp, dev):
+    from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+    reg = ModelRegistrar("/tmp", dev)
+    return MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, []), reg
+
+
+def _to(batch, dev):
+    t = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+    return t["x"], t["x_st"], t["y"], t["y_st"], t.get("lanes"), t.get("map")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("tiny", [True, False])
+def test_predict_matches_reference_golden(mode, tiny):
+    dev = _dev()
+    z, meta = load_golden(("tiny_" if tiny else "full_") + mode)
+    hp, B, ph = hp_for(mode, tiny)
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, tiny, z)
+    x, x_st, y, y_st, lanes, maps = _to(batch_for(mode, tiny), dev)
+    hist, lane = model.predict(x, x_st, lanes, None, maps, ph)
+    pred = (lane if mode == "lane_cnn" else hist).cpu().numpy()
+    node = x[:, -1, 0:2].cpu().numpy()
+    node = node[:, None, None, :] if mode == "lane_cnn" else node[:, None, :]
+    assert np.isfinite(pred).all()
+    assert rel_err((pred - node) / 80.0, (z["predict"] - node) / 80.0) <= TOL
+    # encoder memory
+    memory, pad = reg.model_dict["VEHICLE/node_history_encoder"].forward_with_mask(x_st)
+    m = z["memory"].shape[0]
+    assert rel_err(memory[:m].cpu().numpy(), z["memory"]) <= TOL
+    assert int(pad.sum()) == 0
+    # ADE / FDE through the device reduction
+    from multimodal_transformer_amd.evaluation import batch_ade_fde
+    ade, fde = batch_ade_fde(lane if mode == "lane_cnn" else hist, y)
+    assert np.max(np.abs(ade.cpu().numpy() - z["ade"])) <= 1e-3
+    assert np.max(np.abs(fde.cpu().numpy() - z["fde"])) <= 1e-3
+    # losses (forward values)
+    ev, _ = model.eval_loss("VEHICLE", x, x_st, lanes, None, None, y, y_st, maps, ph)
+    assert abs(float(ev) - float(z["eval_loss"])) <= TOL * abs(float(z["eval_loss"]))
+    tr, _ = model.train_loss(x, x_st, lanes, None, None, y, y_st, maps, ph)
+    assert abs(float(tr) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
+    if "enc_map" in z.files:
+        em = reg.model_dict["VEHICLE/map_encoder"].forward_raw(maps)
+        assert rel_err(em[: z["enc_map"].shape[0]].cpu().numpy(), z["enc_map"]) <= TOL
+    if "enc_lane" in z.files:
+        el = reg.model_dict["VEHICLE/lane_encoder"](lanes.view(-1, 2, 10)).view(B, 3, -1)
+        assert rel_err(el[: z["enc_lane"].shape[0]].cpu().numpy(), z["enc_lane"]) <= TOL
+
+
+def test_teacher_forced_decoder_matches_reference_golden():
+    dev = _dev()
+    z, _ = load_golden("tiny_basic")
+    hp, B, ph = hp_for("basic", True)
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, True, z)
+    y_st = torch.from_numpy(z["in::y_st"]).to(dev)
+    tgt = torch.cat([torch.zeros(B, 1, 2, device=dev), y_st[:, :-1]], dim=1).contiguous()
+    memory = torch.from_numpy(z["memory"]).to(dev)
+    pad = torch.zeros(B, memory.shape[1], dtype=torch.bool, device=dev)
+    dec = reg.model_dict["VEHICLE/decoder/transformer_decoder"]
+    h = dec(tgt, memory, None, None, pad)
+    assert rel_err(h.cpu().numpy(), z["decoder_tf"]) <= TOL
+
+
+def _oracle_predict(hp, reg, batch, ph, n=None):
+    from oracle import restatement as rs     # checker only
+    cpu_modules = {k: v for k, v in reg.model_dict.items()}
+    w = {}
+    alias = {"node_history_encoder": "enc", "decoder/transformer_decoder": "dec", "decoder/MLP": "head",
+             "fusion/hist_map": "fuse_map", "fusion/lane_hist": "fuse_lane", "map_encoder": "map",
+             "lane_encoder": "lane", "Lane/MLP_Softmax": "lane_cls"}
+    for key, mod in cpu_modules.items():
+        short = alias[key.split("/", 1)[1]]
+        for pn, t in mod.state_dict().items():
+            w[f"{short}.{pn}"] = t.detach().double().cpu()
+    t = {k: torch.from_numpy(v[:n]).double() for k, v in batch.items()}
+    return rs.predict(w, hp, t["x"], t["x_st"], t.get("lanes"), t.get("map"), ph).numpy()
+
+
+@pytest.mark.parametrize("mode,B,hist,ph", [
+    ("basic", 1, 8, 12), ("basic", 17, 8, 12), ("basic", 300, 8, 12), ("basic", 5, 4, 8), ("basic", 3, 19, 1),
+    ("basic", 40, 15, 20), ("map_cnn", 9, 8, 12), ("lane_cnn", 7, 8, 12), ("lane_cnn", 33, 3, 5),
+])
+def test_predict_matches_fp64_oracle_on_ragged_shapes(mode, B, hist, ph):
+    """Edge shapes the reference's own configs never hit: batch 1, batches that do not fill a workgroup
+    tile, history lengths below/above one 16-row tile, horizon 1."""
+    dev = _dev()
+    hp = make_hyperparams(mode, history=hist, horizon=ph)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=3)
+    batch = make_batch(B, hist, ph, seed=11, with_map=(mode == "map_cnn"), with_lanes=(mode == "lane_cnn"))
+    x, x_st, y, y_st, lanes, maps = _to(batch, dev)
+    h, lane = model.predict(x, x_st, lanes, None, maps, ph)
+    got = (lane if mode == "lane_cnn" else h).cpu().numpy()
+    n = min(B, 24)
+    want = _oracle_predict(hp, reg, batch, ph, n)
+    node = batch["x"][:n, -1, 0:2]
+    node = node[:, None, None, :] if mode == "lane_cnn" else node[:, None, :]
+    assert rel_err((got[:n] - node) / 80.0, (want - node) / 80.0) <= TOL
+
+
+def test_lane_dedup_equals_three_decodes():
+    dev = _dev()
+    hp = make_hyperparams("lane_cnn", history=8, horizon=12, transformer=TINY_TR)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=5)
+    x, x_st, y, y_st, lanes, maps = _to(make_batch(6, 8, 12, seed=2, with_lanes=True), dev)
+    _, a = model.predict(x, x_st, lanes, None, None, 12)
+    model.lane_dedup = False
+    _, b = model.predict(x, x_st, lanes, None, None, 12)
+    assert torch.equal(a, b)
+    assert torch.equal(b[:, 0], b[:, 1]) and torch.equal(b[:, 0], b[:, 2])
+
+
+def test_padded_history_is_finite_and_masks_are_reported():
+    """Front-padded (NaN) histories are 'undefined in reference' (SURVEY §0.7); here: finite outputs and the
+    padding mask = isnan(x_st[:,:,1])."""
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=12, transformer=TINY_TR)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=5)
+    batch = make_batch(5, 8, 12, seed=2)
+    batch["x_st"][1, :3] = np.nan
+    batch["x_st"][4, :7] = np.nan
+    x, x_st, *_ = _to(batch, dev)
+    memory, pad = reg.model_dict["VEHICLE/node_history_encoder"].forward_with_mask(x_st)
+    want = np.isnan(batch["x_st"][:, :, 1])
+    assert np.array_equal(pad.cpu().numpy().astype(bool), want)
+    hist, _ = model.predict(x, x_st, None, None, None, 12)
+    assert torch.isfinite(hist).all()
+    # un-padded agents are unaffected by their neighbours' padding
+    clean = make_batch(5, 8, 12, seed=2)
+    xc, xc_st, *_ = _to(clean, dev)
+    hist_c, _ = model.predict(xc, xc_st, None, None, None, 12)
+    assert torch.equal(hist[[0, 2, 3]], hist_c[[0, 2, 3]])
+
+
+def test_batch_invariance_and_determinism():
+    """Agents are independent: any split of the batch gives bit-identical rows (the multi-GPU sharding
+    property), and repeated launches are bit-identical."""
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=12)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    x, x_st, *_ = _to(make_batch(128, 8, 12, seed=1), dev)
+    full, _ = model.predict(x, x_st, None, None, None, 12)
+    again, _ = model.predict(x, x_st, None, None, None, 12)
+    assert torch.equal(full, again)
+    parts = [model.predict(x[i:i + 16].contiguous(), x_st[i:i + 16].contiguous(), None, None, None, 12)[0]
+             for i in range(0, 128, 16)]
+    assert torch.equal(full, torch.cat(parts))
+    odd = model.predict(x[:37].contiguous(), x_st[:37].contiguous(), None, None, None, 12)[0]
+    assert torch.equal(full[:37], odd)
+
+
+def test_large_batch_properties():
+    """BASELINE config 5 size on one GPU (8192/8 = 1024 agents): finite, and rows equal the B=128 run."""
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=12)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    x, x_st, *_ = _to(make_batch(1024, 8, 12, seed=1), dev)
+    big, _ = model.predict(x, x_st, None, None, None, 12)
+    assert torch.isfinite(big).all()
+    small, _ = model.predict(x[:128].contiguous(), x_st[:128].contiguous(), None, None, None, 12)
+    # different tile shapes (32-row encoder tiles, 4 agents per decoder workgroup): same arithmetic per row
+    assert rel_err(big[:128].cpu().numpy(), small.cpu().numpy()) <= 1e-6
+
+
+def test_error_paths():
+    from multimodal_transformer_amd._lib import MmtError
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=12, transformer=TINY_TR)
+    model, reg = _model(hp, dev)
+    x, x_st, *_ = _to(make_batch(4, 8, 12, seed=1), dev)
+    with pytest.raises(MmtError):
+        model.predict(x, x_st[:, :, :5].contiguous(), None, None, None, 12)       # wrong feature count
+    with pytest.raises(MmtError):
+        model.predict(x, x_st.double(), None, None, None, 12)                       # wrong dtype
+    with pytest.raises(MmtError):
+        model.predict(x, x_st[:0].contiguous(), None, None, None, 12)               # empty batch
+    with pytest.raises(MmtError):
+        model.predict(x, x_st, None, None, None, 64)                                # horizon beyond the kernel's cap

@@ -64,3 +64,31 @@ def test_reference_form_matches_reference(mode, tiny):
                     assert rel_err(p.grad.numpy(), z[key]) <= 1e-3, key
                 else:
                     assert p.grad is None, key
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("tiny", [True, False])
+def test_kv_cached_restatement_matches_reference(mode, tiny):
+    """oracle/restatement.py (explicit maths, KV cache, fp64) against the reference's goldens."""
+    from oracle import restatement as rs
+    z, meta = load_golden(("tiny_" if tiny else "full_") + mode)
+    hp, B, ph = hp_for(mode, tiny)
+    model = rf.ReferenceFormModel(hp)
+    set_weights(model.m, tiny, z)
+    w = rs.flatten_modules(model.m, dtype=torch.float64)
+    x, x_st, y, y_st, lanes, maps = _tensors(batch_for(mode, tiny))
+    n = B if tiny else 16          # fp64 on CPU: a slice of the full batch is enough
+    d = lambda t: None if t is None else t[:n].double()
+    pred = rs.predict(w, hp, d(x), d(x_st), d(lanes), d(maps), ph).numpy()
+    node = x[:n, -1, 0:2].numpy()
+    node = node[:, None, None, :] if mode == "lane_cnn" else node[:, None, :]
+    assert rel_err((pred - node) / 80.0, (z["predict"][:n] - node) / 80.0) <= TOL
+    mem, _ = rs.encoder_forward(w, d(x_st), hp["transformer"]["nhead"])
+    m = min(n, z["memory"].shape[0])
+    assert rel_err(mem[:m].numpy(), z["memory"][:m]) <= TOL
+    if tiny:
+        tgt = torch.cat([torch.zeros(B, 1, 2), y_st[:, :-1]], dim=1).double()
+        pad = torch.zeros(B, x_st.shape[1], dtype=torch.bool)
+        _, h = rs.decoder_ar(w, torch.from_numpy(z["memory"]).double(), pad, None, hp["transformer"]["nhead"], ph,
+                             feedback=False, tgt=tgt)
+        assert rel_err(h.numpy(), z["decoder_tf"]) <= TOL
