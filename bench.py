@@ -1,0 +1,225 @@
+"""Benchmark of the hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128] [--mode basic] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one `predict` of BASELINE.json configs[0] (Basic transformer --autoregressive predict,
+VEHICLE, 8-step history, 12-step horizon) on a synthetic nuScenes-shaped batch of 128 agents that is
+already resident in HBM.  With N GPUs every rank runs its own batch of 128 (agents are independent:
+no data-path collective; weak scaling) and `value` = N*128*K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     for the dominant kernel (the persistent KV-cached decoder): algorithmic FLOPs per launch
+               (109.91 MFLOP/agent for decoder+head, KV-cached) / its average launch
+               duration measured with HIP events on the launch stream, against the dense fp32 MFMA peak;
+  cpu_baseline the CPU oracle in reference form (stock torch.nn modules, full recompute per step) timed on
+               this box's host cores on the same batch (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from multimodal_transformer_amd.config import make_hyperparams  # noqa: E402
+from multimodal_transformer_amd.synthetic import make_batch  # noqa: E402
+from multimodal_transformer_amd.weights import apply_recipe  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: dense fp32 matrix peak
+# algorithmic MFLOP per agent, KV-cached (SURVEY.md §8d / BASELINE.md §3)
+MFLOP_ENCODER, MFLOP_DECODER, MFLOP_HEAD = 57.16, 109.88, 0.03
+MFLOP_CNN = 11.60
+
+
+class _Env:
+    robot_type = None
+
+
+def build_model(mode, dev, history, horizon):
+    from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+    hp = make_hyperparams(mode, history=history, horizon=horizon)
+    reg = ModelRegistrar("/tmp", dev)
+    model = MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, [])
+    apply_recipe(reg.model_dict, seed=0)
+    return hp, model, reg
+
+
+def time_kernels(model, reg, tensors, ph, iters):
+    """Per-kernel average durations (ms) with HIP events on the stream the kernels are launched on."""
+    from multimodal_transformer_amd import ops
+    x, x_st, lanes, maps = tensors
+    enc = reg.model_dict["VEHICLE/node_history_encoder"]
+    dec = reg.model_dict["VEHICLE/decoder/transformer_decoder"]
+    head = reg.model_dict["VEHICLE/decoder/MLP"]
+    out = {}
+
+    def avg(fn):
+        fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) / iters
+
+    memory, pad = enc.forward_with_mask(x_st)
+    start = x_st[:, -1, 0:2].contiguous()
+    out["encoder_ms"] = avg(lambda: enc.forward_with_mask(x_st))
+    map_feat = fusion = None
+    if maps is not None:
+        me = reg.model_dict["VEHICLE/map_encoder"]
+        map_feat = me.forward_raw(maps)
+        fusion = reg.model_dict["VEHICLE/fusion/hist_map"]
+        out["map_encoder_ms"] = avg(lambda: me.forward_raw(maps))
+    packed = dec.packed(head=head, map_fusion=fusion)
+    out["decoder_ms"] = avg(lambda: ops.decoder_forward(packed, memory, pad, start, ph, map_feat=map_feat))
+    return out
+
+
+def cpu_baseline(mode, hp, batch, ph, max_seconds=25.0):
+    """Oracle in reference form on the host cores: 2 warm-up + up to 5 timed predicts (bounded)."""
+    from oracle import reference_form as rf          # checker / baseline only, never the product path
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    ref = rf.ReferenceFormModel(hp)
+    apply_recipe(ref.m, seed=0)
+    ref.m.eval()
+    c = {k: torch.from_numpy(v) for k, v in batch.items()}
+    B = c["x"].shape[0]
+    times = []
+    t_begin = time.perf_counter()
+    with torch.no_grad():
+        for i in range(7):
+            t0 = time.perf_counter()
+            ref.predict(c["x"], c["x_st"], c.get("lanes"), c.get("map"), ph)
+            dt = time.perf_counter() - t0
+            if i >= 2:
+                times.append(dt)
+            if time.perf_counter() - t_begin > max_seconds and len(times) >= 1:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "agents/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed predicts of the same B={B} batch after 2 warm-ups, median; "
+                      f"oracle/reference_form.py (stock torch.nn modules, full recompute per AR step), "
+                      f"eval mode, no_grad, anomaly detection off; os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=128, help="agents per GPU per step")
+    ap.add_argument("--mode", default="basic", choices=["basic", "map_cnn", "lane_cnn"])
+    ap.add_argument("--history", type=int, default=8)
+    ap.add_argument("--horizon", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also time larger per-GPU batches (extra keys)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, ph = args.batch, args.horizon
+    hp, model, reg = build_model(args.mode, dev, args.history, ph)
+    # every rank gets its own shard of the global synthetic batch (seeded by rank): no collective on the data path
+    batch = make_batch(B, args.history, ph, seed=1 + rank, with_map=(args.mode == "map_cnn"),
+                       with_lanes=(args.mode == "lane_cnn"))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+    x, x_st, lanes, maps = t["x"], t["x_st"], t.get("lanes"), t.get("map")
+
+    def step():
+        return model.predict(x, x_st, lanes, None, maps, ph)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    res = out[1] if args.mode == "lane_cnn" else out[0]
+    assert torch.isfinite(res).all()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        kt = time_kernels(model, reg, (x, x_st, lanes, maps), ph, iters=min(50, max(5, args.steps)))
+        dec_flops = (MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * (1 if args.mode != "lane_cnn" or model.lane_dedup else 3)
+        achieved = dec_flops / (kt["decoder_ms"] * 1e-3) / 1e12
+        line = {
+            "metric": "predicted agents/sec (12-step, batch 128)",
+            "value": value, "unit": "agents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic nuScenes-shaped batch (multimodal_transformer_amd/synthetic.py), "
+                                    "random-init weights from the by-name recipe",
+            "config": {"workload": f"{args.mode} transformer --autoregressive predict, VEHICLE, batch {B} per GPU, "
+                                   f"{args.history}-step history, {ph}-step horizon",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-split x{world}, no collective"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "mmt_decoder_kernel", "avg_launch_ms": kt["decoder_ms"],
+                         "algorithmic_flop_per_launch": dec_flops},
+            "kernels_ms": kt,
+        }
+        if args.sweep and not distributed:
+            sweep = {}
+            for bb in (1024, 4096):
+                bt = make_batch(bb, args.history, ph, seed=7, with_map=(args.mode == "map_cnn"),
+                                with_lanes=(args.mode == "lane_cnn"))
+                tt_ = {k: torch.from_numpy(v).to(dev) for k, v in bt.items()}
+                f = lambda: model.predict(tt_["x"], tt_["x_st"], tt_.get("lanes"), None, tt_.get("map"), ph)
+                for _ in range(3):
+                    f()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n = 10
+                for _ in range(n):
+                    f()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / n
+                sweep[str(bb)] = {"agents_per_s": bb / dt, "ms_per_step": dt * 1e3,
+                                  "mfma_frac": (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * bb / dt / 1e12
+                                  / PEAK_F32_MFMA_TFLOPS}
+            line["batch_sweep"] = sweep
+        if not args.no_cpu_baseline and not distributed:
+            line["cpu_baseline"] = cpu_baseline(args.mode, hp, batch, ph)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
