@@ -14,7 +14,7 @@ MMT_MAX_MLP_HIDDEN = 3
 MMT_MAX_CONV = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmt_amd.so")
+LIB_PATH = os.environ.get("MMT_AMD_LIB", os.path.join(_HERE, "libmmt_amd.so"))   # override: diagnostic builds only
 
 fptr = C.c_void_p
 

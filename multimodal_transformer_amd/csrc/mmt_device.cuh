@@ -16,120 +16,215 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MMT_PAD 8   // row padding (floats) that makes the ds_read_b128 A-operand reads conflict free
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // SGPR: keeps wave-level control flow scalar
 __device__ __forceinline__ int n_waves() { return blockDim.x >> 6; }
 
 __device__ __forceinline__ int round16(int v) { return (v + 15) & ~15; }
 
 // ---------------------------------------------------------------------------------------------
+// Weight streaming registers: one "group" = U consecutive 16-k chunks of SL slabs (SL*U KiB per wave).
+#ifndef MMT_WSL
+#define MMT_WSL 2
+#endif
+#ifndef MMT_WU
+#define MMT_WU 4
+#endif
+#ifndef MMT_NT
+#define MMT_NT 512
+#endif
+constexpr int WSL = MMT_WSL;   // slabs in flight per wave (independent MFMA accumulator chains)
+constexpr int WU = MMT_WU;     // chunks per group
+struct WRegs {
+  f32x4 w[WSL][WU];
+};
+
+struct NextLin {          // the linear that follows in program order (its first group is prefetched)
+  const float *w;
+  int K16, N16;
+};
+__device__ __forceinline__ NextLin next_of(const mmt_linear &L) {
+  return NextLin{L.w, round16(L.k) >> 4, round16(L.n) >> 4};
+}
+__device__ __forceinline__ NextLin no_next() { return NextLin{nullptr, 0, 0}; }
+__device__ __forceinline__ bool fast_geom(int K16) { return K16 >= WU && (K16 % WU) == 0; }
+
+__device__ __forceinline__ void wload(WRegs &r, const f32x4 *W4, int K16, int N16, int s0, int c0) {
+#pragma unroll
+  for (int s = 0; s < WSL; ++s) {
+    const int slab = min(s0 + s, N16 - 1);    // a dead slab re-reads the last one (in bounds, discarded)
+    const f32x4 *p = W4 + ((size_t)slab * K16 + c0) * 64;
+#pragma unroll
+    for (int u = 0; u < WU; ++u) r.w[s][u] = p[(size_t)u * 64];
+  }
+}
+
 // Y[r][n] = epi(r, n, sum_k X[r][k] * W[n][k])  for r < 16*MB, n < N16*16.
 // X: LDS, row stride ldx floats, columns [0, 16*K16) must be finite (zero padded).
-// W: packed weights.  Each wave owns SL consecutive 16-column slabs at a time.
+// W: packed weights.  Each wave owns WSL consecutive 16-column slabs at a time ("slab set").
 // A operand lane (i = lane&15, q = lane>>4) holds X[i][16c + 4q + e], B operand lane (j, q) holds
 // W[16s + j][16c + 4q + e]; MFMA step e sums the four q's, four steps cover the 16 k of a chunk.
 // C/D layout: col = lane&15, row = 4*(lane>>4) + reg.
-template <int MB, int SL, class Epi>
-__device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx,
-                                            const float *__restrict__ Wp, int K16, int N16, Epi epi) {
+// The wave's weight reads form one flat stream (slab set major, k minor) that is software-pipelined one
+// group ahead ACROSS slab sets, and -- through `pre` / `next` -- across the barrier-separated phases of a
+// layer: the first group of the next linear is requested before this one's last MFMAs issue, so the
+// L2/Infinity-Cache latency hides behind the epilogue, the barrier and the LayerNorm/attention phase.
+//   PRE: `pre` already holds this linear's first group (the previous call was given it as `next`).
+template <int MB, bool PRE, class Epi>
+__device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx, const float *__restrict__ Wp,
+                                            int K16, int N16, Epi epi, WRegs &pre, NextLin next) {
   const int lane = lane_id();
   const int nw = n_waves();
+  const int first = wave_id() * WSL;
   const float *xrow = X + (lane & 15) * ldx + (lane >> 4) * 4;
-  for (int s0 = wave_id() * SL; s0 < N16; s0 += nw * SL) {
-    f32x4 acc[SL][MB];
+  const f32x4 *W4 = reinterpret_cast<const f32x4 *>(Wp) + lane;
+  const f32x4 *N4 = reinterpret_cast<const f32x4 *>(next.w) + lane;
+  const bool do_next = next.w != nullptr && fast_geom(next.K16);
+  const int nfirst = min(first, max(next.N16 - 1, 0));
+  f32x4 acc[WSL][MB];
 #pragma unroll
-    for (int s = 0; s < SL; ++s)
+  for (int s = 0; s < WSL; ++s)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Epilogue operands (bias, residual) are requested before the last MFMAs of a slab set so that the
+  // flush itself is add + ds_write with nothing to wait for.
+  typename Epi::template Pre<MB> pb[WSL];
+  auto prep = [&](int s0) {
+#pragma unroll
+    for (int s = 0; s < WSL; ++s) epi.prep(pb[s], (lane >> 4) * 4, min(s0 + s, N16 - 1) * 16 + (lane & 15));
+  };
+  auto flush = [&](int s0) {
+#pragma unroll
+    for (int s = 0; s < WSL; ++s) {
+      if (s0 + s < N16) {
+        const int col = (s0 + s) * 16 + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) epi.store(m * 16 + (lane >> 4) * 4 + r, col, acc[s][m][r], pb[s], m, r);
+      }
 #pragma unroll
       for (int m = 0; m < MB; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f32x4 *wp[SL];
-    bool live[SL];
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      live[s] = (s0 + s) < N16;
-      int slab = live[s] ? (s0 + s) : s0;   // wave-uniform; a dead slab re-reads slab s0 (in bounds)
-      wp[s] = reinterpret_cast<const f32x4 *>(Wp) + (size_t)slab * K16 * 64 + lane;
     }
-    constexpr int U = 4;
-    int c = 0;
-    if (K16 >= U) {
-      f32x4 wcur[SL][U], wnxt[SL][U];
-#pragma unroll
-      for (int s = 0; s < SL; ++s)
-#pragma unroll
-        for (int u = 0; u < U; ++u) wcur[s][u] = wp[s][(size_t)u * 64];
-      for (; c + U <= K16; c += U) {
-        const bool more = (c + 2 * U) <= K16;
-        if (more) {
-#pragma unroll
-          for (int s = 0; s < SL; ++s)
-#pragma unroll
-            for (int u = 0; u < U; ++u) wnxt[s][u] = wp[s][(size_t)(c + U + u) * 64];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          f32x4 xv[MB];
-#pragma unroll
-          for (int m = 0; m < MB; ++m)
-            xv[m] = *reinterpret_cast<const f32x4 *>(xrow + m * 16 * ldx + (c + u) * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int s = 0; s < SL; ++s)
-#pragma unroll
-              for (int m = 0; m < MB; ++m)
-                acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][e], wcur[s][u][e], acc[s][m], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-          for (int s = 0; s < SL; ++s)
-#pragma unroll
-            for (int u = 0; u < U; ++u) wcur[s][u] = wnxt[s][u];
-        }
+  };
+
+  if (fast_geom(K16)) {
+    const int nsets = first < N16 ? (N16 - first + nw * WSL - 1) / (nw * WSL) : 0;
+    const int gps = K16 / WU;
+    const int total = nsets * gps;
+    WRegs cur;
+    if (PRE) cur = pre;
+    else if (total > 0) wload(cur, W4, K16, N16, first, 0);
+    int set = 0, kg = 0;
+    for (int g = 0; g < total; ++g) {
+      int kg1 = kg + 1, set1 = set;
+      if (kg1 == gps) {
+        kg1 = 0;
+        ++set1;
       }
+      WRegs nxt = cur;
+#ifndef MMT_EXP_NOLOAD
+      if (g + 1 < total) wload(nxt, W4, K16, N16, first + set1 * nw * WSL, kg1 * WU);
+      else if (do_next) wload(nxt, N4, next.K16, next.N16, nfirst, 0);
+#endif
+      if (kg == gps - 1) prep(first + set * nw * WSL);
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        f32x4 xv[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          xv[m] = *reinterpret_cast<const f32x4 *>(xrow + m * 16 * ldx + (kg * WU + u) * 16);
+#ifdef MMT_EXP_HALFMFMA
+#define MMT_E_END 2
+#else
+#define MMT_E_END 4
+#endif
+#pragma unroll
+        for (int e = 0; e < MMT_E_END; ++e)
+#pragma unroll
+          for (int s = 0; s < WSL; ++s)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+              acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][e], cur.w[s][u][e], acc[s][m], 0, 0, 0);
+      }
+      if (kg == gps - 1) flush(first + set * nw * WSL);
+      cur = nxt;
+      kg = kg1;
+      set = set1;
     }
-    for (; c < K16; ++c) {   // remainder chunks (K16 not a multiple of 4)
-      f32x4 wv[SL];
+    if (total == 0 && do_next) wload(cur, N4, next.K16, next.N16, nfirst, 0);
+    pre = cur;
+  } else {
+    // small / odd K (input_fc, the 32-wide MLPs): plain loop, no pipelining
+    for (int s0 = first; s0 < N16; s0 += nw * WSL) {
+      prep(s0);
+      for (int c = 0; c < K16; ++c) {
+        f32x4 wv[WSL];
 #pragma unroll
-      for (int s = 0; s < SL; ++s) wv[s] = wp[s][(size_t)c * 64];
-      f32x4 xv[MB];
+        for (int s = 0; s < WSL; ++s) wv[s] = W4[((size_t)min(s0 + s, N16 - 1) * K16 + c) * 64];
+        f32x4 xv[MB];
 #pragma unroll
-      for (int m = 0; m < MB; ++m) xv[m] = *reinterpret_cast<const f32x4 *>(xrow + m * 16 * ldx + c * 16);
+        for (int m = 0; m < MB; ++m) xv[m] = *reinterpret_cast<const f32x4 *>(xrow + m * 16 * ldx + c * 16);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int s = 0; s < SL; ++s)
+          for (int s = 0; s < WSL; ++s)
 #pragma unroll
-          for (int m = 0; m < MB; ++m)
-            acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][e], wv[s][e], acc[s][m], 0, 0, 0);
+            for (int m = 0; m < MB; ++m)
+              acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][e], wv[s][e], acc[s][m], 0, 0, 0);
+      }
+      flush(s0);
     }
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      if (!live[s]) continue;
-      const int col = (s0 + s) * 16 + (lane & 15);
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) epi(m * 16 + (lane >> 4) * 4 + r, col, acc[s][m][r]);
-    }
+    if (do_next) wload(pre, N4, next.K16, next.N16, nfirst, 0);
   }
 }
 
 // Convenience: Y = X W^T + b [+relu] [+= residual already in Y]
 enum { EPI_STORE = 0, EPI_RELU = 1, EPI_ADD = 2 };
 
+template <int MODE>
+struct LdsEpi {
+  const float *__restrict__ bias;
+  float *__restrict__ Y;
+  int n, ldy;
+  template <int MB>
+  struct Pre {
+    float b;
+    float res[MB][4];
+  };
+  // row0 = first of the lane's 4 rows inside a 16-row block, col = the lane's output column
+  template <int MB>
+  __device__ __forceinline__ void prep(Pre<MB> &p, int row0, int col) const {
+    p.b = (bias != nullptr && col < n) ? bias[col] : 0.f;
+    if (MODE == EPI_ADD) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.res[m][r] = col < n ? Y[(m * 16 + row0 + r) * ldy + col] : 0.f;
+    }
+  }
+  template <int MB>
+  __device__ __forceinline__ void store(int r, int c, float v, const Pre<MB> &p, int m, int ri) const {
+    if (c < n) {
+      v += p.b;
+      if (MODE == EPI_RELU) v = fmaxf(v, 0.f);
+      if (MODE == EPI_ADD) v += p.res[m][ri];
+      Y[r * ldy + c] = v;
+    }
+  }
+};
+
+template <int MB, int MODE, bool PRE = false>
+__device__ __forceinline__ void linear_to_lds(const float *X, int ldx, const mmt_linear &L, float *Y, int ldy,
+                                              WRegs &pre, NextLin next) {
+  LdsEpi<MODE> epi{L.b, Y, L.n, ldy};
+  tile_linear<MB, PRE>(X, ldx, L.w, round16(L.k) >> 4, round16(L.n) >> 4, epi, pre, next);
+}
+
 template <int MB, int MODE>
 __device__ __forceinline__ void linear_to_lds(const float *X, int ldx, const mmt_linear &L, float *Y, int ldy) {
-  const float *bias = L.b;
-  const int n = L.n;
-  auto epi = [=](int r, int c, float v) {
-    if (c < n) {
-      if (bias) v += bias[c];
-      if (MODE == EPI_RELU) v = fmaxf(v, 0.f);
-      float *dst = Y + r * ldy + c;
-      if (MODE == EPI_ADD) v += *dst;
-      *dst = v;
-    }
-  };
-  tile_linear<MB, 2>(X, ldx, L.w, round16(L.k) >> 4, round16(L.n) >> 4, epi);
+  WRegs scratch;
+  linear_to_lds<MB, MODE, false>(X, ldx, L, Y, ldy, scratch, no_next());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -161,36 +256,62 @@ __device__ __forceinline__ void layer_norm_rows(float *X, int ldx, int nrows, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// One attention "group" = 16 lanes serving one (query row, head).
-//   q      : pointer to the query's head slice (dh floats, LDS)
+// One attention "group" = 16 lanes serving one (query row, head); DH = head dim (16, 32 or 64).
+//   q      : pointer to the query's head slice (DH floats, LDS)
 //   kbase  : pointer to key 0's head slice, keys are kstride floats apart (LDS or global)
 //   vbase  : same for values
-//   nkeys  : keys 0..nkeys-1 are candidates; key j is masked out when (maskbits >> j) & 1
-//   out    : head slice of the output (dh floats); may alias q
-// Softmax over <= 32 keys is held in registers: lane j owns keys j and j+16.
+//   nkeys  : keys 0..nkeys-1 are candidates (<= 32); key j is masked out when (maskbits >> j) & 1
+//   out    : head slice of the output (DH floats); may alias q
+// Lane j owns keys j and j+16 for the scores and DH/16 contiguous output dims for P.V.  All K loads
+// of a lane and all V loads of the first 16 keys are issued before anything is consumed, so a group
+// costs one memory round trip instead of one per key (the KV cache lives in L2, ~500+ cycles away).
+template <int DH>
 __device__ __forceinline__ void attend_group(const float *q, const float *kbase, const float *vbase,
-                                             int kstride, int nkeys, uint32_t maskbits, int dh, float scale,
-                                             float *out) {
+                                             int kstride, int nkeys, uint32_t maskbits, float scale, float *out) {
+  constexpr int DPL = DH / 16;      // output dims per lane
+  constexpr int NQ = DH / 4;
+  typedef float vrow __attribute__((ext_vector_type(DPL)));
   const int l16 = threadIdx.x & 15;
-  float sc[2];
+  const float *vmine = vbase + l16 * DPL;
+  // V of keys 0..15, my dims (keys >= nkeys: not loaded)
+  float vr[16][DPL];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int j = 0; j < 16; ++j) {
+    if (j < nkeys) {
+      if constexpr (DPL == 1) {
+        vr[j][0] = vmine[(size_t)j * kstride];
+      } else {
+        const vrow t = *reinterpret_cast<const vrow *>(vmine + (size_t)j * kstride);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) vr[j][e] = t[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) vr[j][e] = 0.f;
+    }
+  }
+  f32x4 qv[NQ];
+#pragma unroll
+  for (int c = 0; c < NQ; ++c) qv[c] = *reinterpret_cast<const f32x4 *>(q + 4 * c);
+  float sc[2] = {-INFINITY, -INFINITY};
+  const int nhalf = nkeys > 16 ? 2 : 1;
+  for (int h = 0; h < nhalf; ++h) {
     const int j = l16 + 16 * h;
-    float s = -INFINITY;
     if (j < nkeys && !((maskbits >> j) & 1u)) {
       const float *k = kbase + (size_t)j * kstride;
+      f32x4 kr[NQ];
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) kr[c] = *reinterpret_cast<const f32x4 *>(k + 4 * c);
       float a = 0.f;
-      for (int c = 0; c < dh; c += 4) {
-        const f32x4 kv = *reinterpret_cast<const f32x4 *>(k + c);
-        const f32x4 qv = *reinterpret_cast<const f32x4 *>(q + c);
-        a = fmaf(qv[0], kv[0], a);
-        a = fmaf(qv[1], kv[1], a);
-        a = fmaf(qv[2], kv[2], a);
-        a = fmaf(qv[3], kv[3], a);
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        a = fmaf(qv[c][0], kr[c][0], a);
+        a = fmaf(qv[c][1], kr[c][1], a);
+        a = fmaf(qv[c][2], kr[c][2], a);
+        a = fmaf(qv[c][3], kr[c][3], a);
       }
-      s = a * scale;
+      if (h == 0) sc[0] = a * scale; else sc[1] = a * scale;
     }
-    sc[h] = s;
   }
   float mx = fmaxf(sc[0], sc[1]);
 #pragma unroll
@@ -206,21 +327,24 @@ __device__ __forceinline__ void attend_group(const float *q, const float *kbase,
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
   p0 *= inv;
   p1 *= inv;
-  // P.V : lane owns output dims l16, l16+16, ... (< dh)
-  float o_acc[4] = {0.f, 0.f, 0.f, 0.f};   // dh <= 64
-  for (int j = 0; j < nkeys; ++j) {
-    const float pj = __shfl(j < 16 ? p0 : p1, j & 15, 16);
-    if (!(pj > 0.f)) continue;   // masked keys may hold non-finite values: never touch them
-    const float *v = vbase + (size_t)j * kstride;
+  float o_acc[DPL];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int c = l16 + 16 * t;
-      if (c < dh) o_acc[t] = fmaf(pj, v[c], o_acc[t]);
+  for (int e = 0; e < DPL; ++e) o_acc[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float pj = __shfl(p0, j, 16);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) o_acc[e] = pj > 0.f ? fmaf(pj, vr[j][e], o_acc[e]) : o_acc[e];
+  }
+  if (nkeys > 16) {       // rare: history / horizon beyond 16 tokens
+    for (int j = 16; j < nkeys; ++j) {
+      const float pj = __shfl(p1, j - 16, 16);
+      if (pj > 0.f) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o_acc[e] = fmaf(pj, vmine[(size_t)j * kstride + e], o_acc[e]);
+      }
     }
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = l16 + 16 * t;
-    if (c < dh) out[c] = o_acc[t];
-  }
+  for (int e = 0; e < DPL; ++e) out[l16 * DPL + e] = o_acc[e];
 }

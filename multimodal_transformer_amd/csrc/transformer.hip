@@ -10,18 +10,58 @@
 //                               inside the kernel.                                (mgcvae.py:375-449)
 #include "mmt_device.cuh"
 
+#ifdef MMT_PROFILE
+__device__ unsigned long long g_prof[512];
+#define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s == (ph / 2)) g_prof[L * 16 + (k)] = clock64(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
+
+// input_fc epilogues: + bias + positional encoding (Transformer_model.py:48-49 / :100-102)
+struct EncInEpi {
+  const float *__restrict__ bias, *__restrict__ pe;
+  float *__restrict__ xs;
+  int d, T, ldx;
+  template <int M>
+  struct Pre {
+    float b;
+  };
+  template <int M>
+  __device__ __forceinline__ void prep(Pre<M> &p, int, int c) const { p.b = c < d ? bias[c] : 0.f; }
+  template <int M>
+  __device__ __forceinline__ void store(int r, int c, float v, const Pre<M> &p, int, int) const {
+    if (c < d) xs[r * ldx + c] = v + p.b + pe[(r % T) * d + c];
+  }
+};
+struct DecInEpi {
+  const float *__restrict__ bias, *__restrict__ pe;   // pe already offset to the current step's row
+  float *__restrict__ xs;
+  int d, ldx;
+  template <int M>
+  struct Pre {
+    float b;
+  };
+  template <int M>
+  __device__ __forceinline__ void prep(Pre<M> &p, int, int c) const { p.b = c < d ? bias[c] + pe[c] : 0.f; }
+  template <int M>
+  __device__ __forceinline__ void store(int r, int c, float v, const Pre<M> &p, int, int) const {
+    if (c < d) xs[r * ldx + c] = v + p.b;
+  }
+};
 
 struct EncLaunch {
   int B, T, ldx, ldb, apw;   // apw = agents per workgroup
 };
 
-template <int MB>
-__global__ __launch_bounds__(512) void mmt_encoder_kernel(mmt_encoder E, EncLaunch P, const float *__restrict__ x_st,
+template <int MB, int DH>
+__global__ __launch_bounds__(MMT_NT) void mmt_encoder_kernel(mmt_encoder E, EncLaunch P, const float *__restrict__ x_st,
                                                           float *__restrict__ memory, uint8_t *__restrict__ pad_out) {
   extern __shared__ __align__(16) float smem[];
   constexpr int MT = 16 * MB;
-  const int d = E.d_model, H = E.nhead, dh = d / H, T = P.T, ldx = P.ldx, ldb = P.ldb;
+  const int d = E.d_model, H = E.nhead, T = P.T, ldx = P.ldx, ldb = P.ldb;
+  constexpr int dh = DH;
   float *xs = smem;
   float *buf = xs + MT * ldx;
   uint32_t *padbits = reinterpret_cast<uint32_t *>(buf + MT * ldb);
@@ -52,33 +92,33 @@ __global__ __launch_bounds__(512) void mmt_encoder_kernel(mmt_encoder E, EncLaun
     padbits[tid] = bits;
   }
   __syncthreads();
+  WRegs pre;
   {
-    const float *bias = E.input_fc.b, *pe = E.pe;
-    auto epi = [=](int r, int c, float v) {
-      if (c < d) xs[r * ldx + c] = v + bias[c] + pe[(r % T) * d + c];
-    };
-    tile_linear<MB, 2>(buf, ldb, E.input_fc.w, round16(E.n_in) >> 4, round16(d) >> 4, epi);
+    EncInEpi epi{E.input_fc.b, E.pe, xs, d, T, ldx};
+    tile_linear<MB, false>(buf, ldb, E.input_fc.w, round16(E.n_in) >> 4, round16(d) >> 4, epi, pre,
+                           next_of(E.layer[0].qkv));
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)dh);
   for (int L = 0; L < E.nlayers; ++L) {
     const mmt_enc_layer &W = E.layer[L];
-    linear_to_lds<MB, EPI_STORE>(xs, ldx, W.qkv, buf, ldb);
+    linear_to_lds<MB, EPI_STORE, true>(xs, ldx, W.qkv, buf, ldb, pre, next_of(W.out));
     __syncthreads();
     for (int g = tid >> 4; g < nrows * H; g += nt >> 4) {
       const int r = g / H, h = g - r * H, a = r / T, t = r - a * T;
       float *q = buf + r * ldb + h * dh;
       const float *kb = buf + (a * T) * ldb + d + h * dh;
-      attend_group(q, kb, kb + d, ldb, t + 1, padbits[a], dh, scale, q);   // causal: keys 0..t
+      attend_group<DH>(q, kb, kb + d, ldb, t + 1, padbits[a], scale, q);   // causal: keys 0..t
     }
     __syncthreads();
-    linear_to_lds<MB, EPI_ADD>(buf, ldb, W.out, xs, ldx);
+    linear_to_lds<MB, EPI_ADD, true>(buf, ldb, W.out, xs, ldx, pre, next_of(W.ff1));
     __syncthreads();
     layer_norm_rows<false>(xs, ldx, nrows, d, W.ln1);
     __syncthreads();
-    linear_to_lds<MB, EPI_RELU>(xs, ldx, W.ff1, buf, ldb);
+    linear_to_lds<MB, EPI_RELU, true>(xs, ldx, W.ff1, buf, ldb, pre, next_of(W.ff2));
     __syncthreads();
-    linear_to_lds<MB, EPI_ADD>(buf, ldb, W.ff2, xs, ldx);
+    linear_to_lds<MB, EPI_ADD, true>(buf, ldb, W.ff2, xs, ldx, pre,
+                                     L + 1 < E.nlayers ? next_of(E.layer[L + 1].qkv) : no_next());
     __syncthreads();
     layer_norm_rows<false>(xs, ldx, nrows, d, W.ln2);
     __syncthreads();
@@ -111,7 +151,8 @@ __device__ __forceinline__ void mlp_stack_tile(const mmt_mlp &M, float *cur, flo
   __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void mmt_decoder_kernel(mmt_decoder D, DecLaunch P, const float *__restrict__ memory,
+template <int DH>
+__global__ __launch_bounds__(MMT_NT) void mmt_decoder_kernel(mmt_decoder D, DecLaunch P, const float *__restrict__ memory,
                                                           const uint8_t *__restrict__ pad_mask,
                                                           const float *__restrict__ start_pos,
                                                           const float *__restrict__ map_feat,
@@ -120,7 +161,8 @@ __global__ __launch_bounds__(512) void mmt_decoder_kernel(mmt_decoder D, DecLaun
                                                           float *__restrict__ h_out, float *__restrict__ memkv,
                                                           float *__restrict__ selfkv) {
   extern __shared__ __align__(16) float smem[];
-  const int d = D.d_model, H = D.nhead, dh = d / H, T = P.T, ph = P.ph, ldx = P.ldx, ldb = P.ldb, B = P.B;
+  const int d = D.d_model, H = D.nhead, T = P.T, ph = P.ph, ldx = P.ldx, ldb = P.ldb, B = P.B;
+  constexpr int dh = DH;
   const int nin = D.n_in, nout = D.n_out;
   float *xs = smem;                      // [16][ldx]   residual stream of the current token
   float *buf = xs + 16 * ldx;            // [16][ldb]   qkv / q / ffn hidden / small MLP scratch
@@ -186,6 +228,7 @@ __global__ __launch_bounds__(512) void mmt_decoder_kernel(mmt_decoder D, DecLaun
   __syncthreads();
 
   // ---- ph autoregressive steps, one new token per agent per step
+  WRegs pre;
   for (int s = 0; s < ph; ++s) {
     for (int i = tid; i < 16 * 16; i += nt) {
       const int r = i >> 4, c = i & 15;
@@ -195,58 +238,70 @@ __global__ __launch_bounds__(512) void mmt_decoder_kernel(mmt_decoder D, DecLaun
     }
     __syncthreads();
     {
-      const float *bias = D.input_fc.b, *pe = D.pe + (size_t)s * d;
-      auto epi = [=](int r, int c, float v) {
-        if (c < d) xs[r * ldx + c] = v + bias[c] + pe[c];
-      };
-      tile_linear<1, 2>(buf, ldb, D.input_fc.w, round16(nin) >> 4, round16(d) >> 4, epi);
+      DecInEpi epi{D.input_fc.b, D.pe + (size_t)s * d, xs, d, ldx};
+      tile_linear<1, false>(buf, ldb, D.input_fc.w, round16(nin) >> 4, round16(d) >> 4, epi, pre,
+                            next_of(D.layer[0].qkv));
     }
     __syncthreads();
     for (int L = 0; L < D.nlayers; ++L) {
       const mmt_dec_layer &W = D.layer[L];
+      STAMP(0);
       // self attention on the KV cache
-      linear_to_lds<1, EPI_STORE>(xs, ldx, W.qkv, buf, ldb);
+      linear_to_lds<1, EPI_STORE, true>(xs, ldx, W.qkv, buf, ldb, pre, next_of(W.out));
       __syncthreads();
+      STAMP(1);
       float *cache = selfkv + ((size_t)L * B + a0) * ph * 2 * d;
       for (int i = tid; i < na * 2 * d; i += nt) {
         const int r = i / (2 * d), c = i - r * 2 * d;
         cache[((size_t)r * ph + s) * 2 * d + c] = buf[r * ldb + d + c];
       }
       __syncthreads();
+      STAMP(2);
       for (int g = tid >> 4; g < na * H; g += nt >> 4) {
         const int r = g / H, h = g - r * H;
         float *q = buf + r * ldb + h * dh;
         const float *kb = cache + (size_t)r * ph * 2 * d + h * dh;
-        attend_group(q, kb, kb + d, 2 * d, s + 1, 0u, dh, scale, q);
+        attend_group<DH>(q, kb, kb + d, 2 * d, s + 1, 0u, scale, q);
       }
       __syncthreads();
-      linear_to_lds<1, EPI_ADD>(buf, ldb, W.out, xs, ldx);
+      STAMP(3);
+      linear_to_lds<1, EPI_ADD, true>(buf, ldb, W.out, xs, ldx, pre, next_of(W.cq));
       __syncthreads();
+      STAMP(4);
       layer_norm_rows<false>(xs, ldx, na, d, W.ln1);
       __syncthreads();
+      STAMP(5);
       // cross attention on the precomputed memory K/V; only key padding masks it (memory_mask is dropped)
-      linear_to_lds<1, EPI_STORE>(xs, ldx, W.cq, buf, ldb);
+      linear_to_lds<1, EPI_STORE, true>(xs, ldx, W.cq, buf, ldb, pre, next_of(W.cout));
       __syncthreads();
+      STAMP(6);
       const float *mkv = memkv + ((size_t)L * B + a0) * T * 2 * d;
       for (int g = tid >> 4; g < na * H; g += nt >> 4) {
         const int r = g / H, h = g - r * H;
         float *q = buf + r * ldb + h * dh;
         const float *kb = mkv + (size_t)r * T * 2 * d + h * dh;
-        attend_group(q, kb, kb + d, 2 * d, T, padbits[r], dh, scale, q);
+        attend_group<DH>(q, kb, kb + d, 2 * d, T, padbits[r], scale, q);
       }
       __syncthreads();
-      linear_to_lds<1, EPI_ADD>(buf, ldb, W.cout, xs, ldx);
+      STAMP(7);
+      linear_to_lds<1, EPI_ADD, true>(buf, ldb, W.cout, xs, ldx, pre, next_of(W.ff1));
       __syncthreads();
+      STAMP(8);
       layer_norm_rows<false>(xs, ldx, na, d, W.ln2);
       __syncthreads();
-      linear_to_lds<1, EPI_RELU>(xs, ldx, W.ff1, buf, ldb);
+      STAMP(9);
+      linear_to_lds<1, EPI_RELU, true>(xs, ldx, W.ff1, buf, ldb, pre, next_of(W.ff2));
       __syncthreads();
-      linear_to_lds<1, EPI_ADD>(buf, ldb, W.ff2, xs, ldx);
+      STAMP(10);
+      linear_to_lds<1, EPI_ADD, true>(buf, ldb, W.ff2, xs, ldx, pre,
+                                      L + 1 < D.nlayers ? next_of(D.layer[L + 1].qkv) : next_of(D.output_fc));
       __syncthreads();
+      STAMP(11);
       layer_norm_rows<false>(xs, ldx, na, d, W.ln3);
       __syncthreads();
+      STAMP(12);
     }
-    linear_to_lds<1, EPI_STORE>(xs, ldx, D.output_fc, regA, ldb);
+    linear_to_lds<1, EPI_STORE, true>(xs, ldx, D.output_fc, regA, ldb, pre, no_next());
     __syncthreads();
     if (h_out)
       for (int i = tid; i < na * nout; i += nt) {
@@ -350,6 +405,11 @@ static int check_launch(const char *what) {
 
 extern "C" const char *mmt_last_error(void) { return g_err; }
 extern "C" int mmt_version(void) { return 1; }
+#ifdef MMT_PROFILE
+extern "C" int mmt_debug_read_prof(unsigned long long *host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" size_t mmt_packed_linear_floats(int n, int k) {
   return (size_t)((n + 15) & ~15) * (size_t)((k + 15) & ~15);
@@ -375,7 +435,7 @@ static int check_tf(int d, int H, int f, int L, const char *who) {
   if (d <= 0 || H <= 0 || d % H || L <= 0 || L > MMT_MAX_LAYERS || f <= 0)
     return fail(MMT_EINVAL, "%s: bad transformer config d=%d H=%d f=%d L=%d", who, d, H, f, L);
   const int dh = d / H;
-  if (d % 16 || dh % 4 || dh > 64) return fail(MMT_EINVAL, "%s: need d%%16==0, head dim %%4==0 and <=64 (d=%d dh=%d)", who, d, dh);
+  if (d % 16 || (dh != 16 && dh != 32 && dh != 64)) return fail(MMT_EINVAL, "%s: need d%%16==0 and head dim 16, 32 or 64 (d=%d dh=%d)", who, d, dh);
   return MMT_OK;
 }
 
@@ -403,13 +463,20 @@ extern "C" int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, in
   const size_t lds = ((size_t)MT * (P.ldx + P.ldb) + 64) * sizeof(float);
   if (lds > 160 * 1024) return fail(MMT_EINVAL, "mmt_encoder_forward: tile needs %zu B of LDS (> 160 KiB)", lds);
   const int grid = (B + P.apw - 1) / P.apw;
+  const int dh = d / enc->nhead;
+#define ENC_LAUNCH(MBV, DHV)                                                                                      \
+  do {                                                                                                            \
+    (void)hipFuncSetAttribute((const void *)mmt_encoder_kernel<MBV, DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                          \
+    hipLaunchKernelGGL((mmt_encoder_kernel<MBV, DHV>), dim3(grid), dim3(MMT_NT), lds, (hipStream_t)stream, *enc, P,   \
+                       x_st, memory, pad_mask);                                                                   \
+  } while (0)
   if (MB == 1) {
-    (void)hipFuncSetAttribute((const void *)mmt_encoder_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mmt_encoder_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, *enc, P, x_st, memory, pad_mask);
+    if (dh == 16) ENC_LAUNCH(1, 16); else if (dh == 32) ENC_LAUNCH(1, 32); else ENC_LAUNCH(1, 64);
   } else {
-    (void)hipFuncSetAttribute((const void *)mmt_encoder_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(mmt_encoder_kernel<2>, dim3(grid), dim3(512), lds, (hipStream_t)stream, *enc, P, x_st, memory, pad_mask);
+    if (dh == 16) ENC_LAUNCH(2, 16); else if (dh == 32) ENC_LAUNCH(2, 32); else ENC_LAUNCH(2, 64);
   }
+#undef ENC_LAUNCH
   return check_launch("mmt_encoder_forward");
 }
 
@@ -471,9 +538,16 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   const int grid = (B + P.apw - 1) / P.apw;
   float *memkv = workspace;
   float *selfkv = workspace + (size_t)dec->nlayers * B * T * 2 * d;
-  (void)hipFuncSetAttribute((const void *)mmt_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mmt_decoder_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, *dec, P, memory, pad_mask,
-                     start_pos, map_feat, mem_feat, tgt, pred_st, h_out, memkv, selfkv);
+  const int dh = d / dec->nhead;
+#define DEC_LAUNCH(DHV)                                                                                             \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void *)mmt_decoder_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                              (int)lds);                                                                            \
+    hipLaunchKernelGGL((mmt_decoder_kernel<DHV>), dim3(grid), dim3(MMT_NT), lds, (hipStream_t)stream, *dec, P, memory,  \
+                       pad_mask, start_pos, map_feat, mem_feat, tgt, pred_st, h_out, memkv, selfkv);                \
+  } while (0)
+  if (dh == 16) DEC_LAUNCH(16); else if (dh == 32) DEC_LAUNCH(32); else DEC_LAUNCH(64);
+#undef DEC_LAUNCH
   return check_launch("mmt_decoder_forward");
 }
 
