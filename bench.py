@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="agents per GPU per step")
-    ap.add_argument("--mode", default="basic", choices=["basic", "map_cnn", "lane_cnn"])
+    ap.add_argument("--mode", default="basic", choices=["basic", "map_cnn", "map_vit", "lane_cnn"])
     ap.add_argument("--history", type=int, default=8)
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +142,7 @@ def main():
     B, ph = args.batch, args.horizon
     hp, model, reg = build_model(args.mode, dev, args.history, ph)
     # every rank gets its own shard of the global synthetic batch (seeded by rank): no collective on the data path
-    batch = make_batch(B, args.history, ph, seed=1 + rank, with_map=(args.mode == "map_cnn"),
+    batch = make_batch(B, args.history, ph, seed=1 + rank, with_map=(args.mode in ("map_cnn", "map_vit")),
                        with_lanes=(args.mode == "lane_cnn"))
     t = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
     x, x_st, lanes, maps = t["x"], t["x_st"], t.get("lanes"), t.get("map")
@@ -195,7 +195,7 @@ def main():
         if args.sweep and not distributed:
             sweep = {}
             for bb in (1024, 4096):
-                bt = make_batch(bb, args.history, ph, seed=7, with_map=(args.mode == "map_cnn"),
+                bt = make_batch(bb, args.history, ph, seed=7, with_map=(args.mode in ("map_cnn", "map_vit")),
                                 with_lanes=(args.mode == "lane_cnn"))
                 tt_ = {k: torch.from_numpy(v).to(dev) for k, v in bt.items()}
                 f = lambda: model.predict(tt_["x"], tt_["x_st"], tt_.get("lanes"), None, tt_.get("map"), ph)

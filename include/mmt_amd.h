@@ -107,6 +107,26 @@ typedef struct {
   const float *conv_w, *conv_b, *fc_w, *fc_b;   /* plain layouts */
 } mmt_lane;
 
+/* vit_pytorch==0.33.2 ViT (third-party; call sites mgcvae.py:145-155,294-296): pre-norm blocks, cls pooling.
+ * Sub-matrices are packed separately so that one workgroup can run attention head-group by head-group:
+ *   qkv.w : [group][q,k,v] each packed (heads_per_group*dim_head x dim), no bias
+ *   out.w : [group] K-slices, each packed (dim x heads_per_group*dim_head); out.b = bias (dim)
+ *   patch_fc.w : [panel] K-slices of the (dim x channels*patch^2) weight, each packed (dim x panel_k) */
+typedef struct {
+  mmt_norm ln1, ln2;
+  mmt_linear qkv, out, ff1, ff2;
+} mmt_vit_block;
+
+typedef struct {
+  int32_t image, patch, channels, dim, depth, heads, dim_head, mlp_dim, n_out, heads_per_group, panel_k;
+  int32_t input_affine;                      /* 1: apply map*2-1 while gathering patches (mgcvae.py:296) */
+  mmt_linear patch_fc;
+  const float *cls_token, *pos_embedding;    /* (dim), (n_patches+1, dim) */
+  mmt_vit_block block[MMT_MAX_LAYERS];
+  mmt_norm head_ln;
+  mmt_linear head_fc;
+} mmt_vit;
+
 const char *mmt_last_error(void);
 int mmt_version(void);
 
@@ -136,6 +156,9 @@ int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8
 /* ---- CNNMapEncoder.forward on map*2-1 (map_encoder.py:31-36, mgcvae.py:288-290) ------------------ */
 size_t mmt_cnn_workspace_floats(const mmt_cnn *cnn, int B);
 int mmt_cnn_forward(const mmt_cnn *cnn, const float *maps, int B, float *out, float *workspace, void *stream);
+
+/* ---- ViT.forward (vit_pytorch 0.33.2 architecture; parity unpinned): maps (B,C,S,S) -> (B,n_out) ------------ */
+int mmt_vit_forward(const mmt_vit *vit, const float *maps, int B, float *out, void *stream);
 
 /* ---- Lane_Encoder.forward on the raw (B*L, 2, S) view (Lane_encoder.py:29-33, mgcvae.py:301-306) -- */
 int mmt_lane_forward(const mmt_lane *lane, const float *lanes, int n_rows, float *out, void *stream);

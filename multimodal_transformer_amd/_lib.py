@@ -66,6 +66,17 @@ class Lane(C.Structure):
                 ("fc_b", fptr)]
 
 
+class VitBlock(C.Structure):
+    _fields_ = [("ln1", Norm), ("ln2", Norm), ("qkv", Linear), ("out", Linear), ("ff1", Linear), ("ff2", Linear)]
+
+
+class Vit(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("image", "patch", "channels", "dim", "depth", "heads", "dim_head", "mlp_dim",
+                                         "n_out", "heads_per_group", "panel_k", "input_affine")] + \
+               [("patch_fc", Linear), ("cls_token", fptr), ("pos_embedding", fptr),
+                ("block", VitBlock * MMT_MAX_LAYERS), ("head_ln", Norm), ("head_fc", Linear)]
+
+
 # symbol -> (restype, argtypes); tests check that the library exports exactly these
 SIGNATURES = {
     "mmt_last_error": (C.c_char_p, []),
@@ -78,6 +89,7 @@ SIGNATURES = {
                                       C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
     "mmt_cnn_workspace_floats": (C.c_size_t, [C.POINTER(Cnn), C.c_int]),
     "mmt_cnn_forward": (C.c_int, [C.POINTER(Cnn), fptr, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_vit_forward": (C.c_int, [C.POINTER(Vit), fptr, C.c_int, fptr, C.c_void_p]),
     "mmt_lane_forward": (C.c_int, [C.POINTER(Lane), fptr, C.c_int, fptr, C.c_void_p]),
     "mmt_finalize": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_void_p]),
 }

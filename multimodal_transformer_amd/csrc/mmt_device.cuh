@@ -180,7 +180,7 @@ __device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx
 }
 
 // Convenience: Y = X W^T + b [+relu] [+= residual already in Y]
-enum { EPI_STORE = 0, EPI_RELU = 1, EPI_ADD = 2 };
+enum { EPI_STORE = 0, EPI_RELU = 1, EPI_ADD = 2, EPI_GELU = 3 };
 
 template <int MODE>
 struct LdsEpi {
@@ -208,6 +208,7 @@ struct LdsEpi {
     if (c < n) {
       v += p.b;
       if (MODE == EPI_RELU) v = fmaxf(v, 0.f);
+      if (MODE == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // nn.GELU() (exact erf form)
       if (MODE == EPI_ADD) v += p.res[m][ri];
       Y[r * ldy + c] = v;
     }
@@ -252,6 +253,29 @@ __device__ __forceinline__ void layer_norm_rows(float *X, int ldx, int nrows, in
       if (RELU) y = fmaxf(y, 0.f);
       x[c] = y;
     }
+  }
+}
+
+// LayerNorm of rows [0, nrows) of src into dst (different LDS tiles, same column count).
+__device__ __forceinline__ void layer_norm_rows_to(const float *S, int lds, float *Dst, int ldd, int nrows, int n,
+                                                   const mmt_norm &N) {
+  const int lane = lane_id();
+  for (int r = wave_id(); r < nrows; r += n_waves()) {
+    const float *x = S + r * lds;
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += x[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s / (float)n;
+    float v = 0.f;
+    for (int c = lane; c < n; c += 64) {
+      float d = x[c] - mu;
+      v += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float rstd = 1.0f / sqrtf(v / (float)n + MMT_LN_EPS);
+    for (int c = lane; c < n; c += 64) Dst[r * ldd + c] = (x[c] - mu) * rstd * N.g[c] + N.b[c];
   }
 }
 

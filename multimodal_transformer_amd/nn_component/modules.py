@@ -274,8 +274,29 @@ class ViT(_PackedMixin, nn.Module):
         self.transformer.layers = nn.ModuleList(blocks)
         self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
 
+    def _cfg(self):
+        cfg = getattr(self, "cfg", None)
+        if cfg is None:       # object unpickled from a vit_pytorch checkpoint: recover the geometry from tensors
+            sd = self.state_dict()
+            dim = sd["cls_token"].shape[-1]
+            inner = sd["transformer.layers.0.0.fn.to_qkv.weight"].shape[0] // 3
+            heads = self.transformer.layers[0][0].fn.heads
+            depth = len(self.transformer.layers)
+            patch_dim = sd["to_patch_embedding.1.weight"].shape[1]
+            n_tok = sd["pos_embedding"].shape[1]
+            side = int(round((n_tok - 1) ** 0.5))
+            patch = int(round((patch_dim / 3) ** 0.5))
+            cfg = dict(image_size=side * patch, patch_size=patch, dim=dim, depth=depth, heads=heads,
+                       dim_head=inner // heads, mlp_dim=sd["transformer.layers.0.1.fn.net.0.weight"].shape[0],
+                       channels=3, num_classes=sd["mlp_head.1.weight"].shape[0])
+        return cfg
+
     def forward(self, img):
-        raise MmtError("call forward_raw(map) -- the kernel fuses the map*2-1 rescale (mgcvae.py:296)")
+        """img is the already rescaled ``map*2-1`` raster, as in the reference's call (mgcvae.py:295-296)."""
+        cfg = self._cfg()
+        return ops.vit_forward(self._packed(lambda sd: ops.PackedVit(sd, cfg)), img.contiguous(), input_affine=False)
 
     def forward_raw(self, maps):
-        raise MmtError("the ViT map encoder kernel is not built yet")
+        """maps in [0,1]; ``*2-1`` is applied while the patches are gathered."""
+        cfg = self._cfg()
+        return ops.vit_forward(self._packed(lambda sd: ops.PackedVit(sd, cfg)), maps.contiguous(), input_affine=True)

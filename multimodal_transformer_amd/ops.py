@@ -290,6 +290,81 @@ class PackedCnn:
         self.desc = N
 
 
+class PackedVit:
+    """vit_pytorch 0.33.2 ``ViT`` descriptor (state_dict names of that package; parity unpinned)."""
+
+    HEADS_PER_GROUP = 2
+    PANEL_K = 256
+
+    def __init__(self, sd: dict, cfg: dict):
+        dev = sd["cls_token"].device
+        pk = _Packer(dev)
+        V = _lib.Vit()
+        dim, heads, dh = cfg["dim"], cfg["heads"], cfg["dim_head"]
+        inner = heads * dh
+        hg = self.HEADS_PER_GROUP if heads % self.HEADS_PER_GROUP == 0 else 1
+        gw = hg * dh
+        V.image, V.patch, V.channels = cfg["image_size"], cfg["patch_size"], cfg["channels"]
+        V.dim, V.depth, V.heads, V.dim_head, V.mlp_dim = dim, cfg["depth"], heads, dh, cfg["mlp_dim"]
+        V.n_out, V.heads_per_group, V.panel_k = cfg["num_classes"], hg, self.PANEL_K
+        if V.depth > _lib.MMT_MAX_LAYERS:
+            raise MmtError(f"ViT depth {V.depth} > {_lib.MMT_MAX_LAYERS}")
+        wp, bp = sd["to_patch_embedding.1.weight"], sd["to_patch_embedding.1.bias"]
+        patch_dim = wp.shape[1]
+        npanel = (patch_dim + self.PANEL_K - 1) // self.PANEL_K
+        # grouped sub-matrices must be back to back in the arena: their biases are packed separately
+        panels = [pk.linear(wp, None, col0=i * self.PANEL_K, k=min(self.PANEL_K, patch_dim - i * self.PANEL_K))
+                  for i in range(npanel)]
+        patch_bias = pk.plain(bp)
+        cls, pos = pk.plain(sd["cls_token"]), pk.plain(sd["pos_embedding"])
+        blocks = []
+        for i in range(V.depth):
+            a, f = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1."
+            wq = sd[a + "fn.to_qkv.weight"]
+            qkv = [pk.linear(wq, None, row0=t * inner + g * gw, n=gw) for g in range(heads // hg) for t in range(3)]
+            wo, bo = sd[a + "fn.to_out.0.weight"], sd[a + "fn.to_out.0.bias"]
+            outs = [pk.linear(wo, None, col0=g * gw, k=gw) for g in range(heads // hg)]
+            blocks.append(dict(
+                out_bias=pk.plain(bo),
+                ln1=pk.norm(sd[a + "norm.weight"], sd[a + "norm.bias"]), qkv=qkv, out=outs,
+                ln2=pk.norm(sd[f + "norm.weight"], sd[f + "norm.bias"]),
+                ff1=pk.linear(sd[f + "fn.net.0.weight"], sd[f + "fn.net.0.bias"]),
+                ff2=pk.linear(sd[f + "fn.net.3.weight"], sd[f + "fn.net.3.bias"])))
+        hln = pk.norm(sd["mlp_head.0.weight"], sd["mlp_head.0.bias"])
+        hfc = pk.linear(sd["mlp_head.1.weight"], sd["mlp_head.1.bias"])
+        self.arena = pk.finish()
+
+        def contiguous(lins, what):
+            step = 4 * (((_r16(lins[0].n) * _r16(lins[0].k)) + 63) & ~63)
+            for a_, b_ in zip(lins, lins[1:]):
+                if b_.w - a_.w != step:
+                    raise MmtError(f"internal: {what} sub-matrices are not contiguous in the arena")
+            if step != 4 * _r16(lins[0].n) * _r16(lins[0].k):
+                raise MmtError(f"internal: {what} packed size is not 64-float aligned")
+
+        contiguous(panels, "panel")
+        _copy_struct(V.patch_fc, panels[0])
+        V.patch_fc.k = patch_dim
+        V.patch_fc.b = patch_bias[0]
+        V.cls_token, V.pos_embedding = cls[0], pos[0]
+        for i, blk in enumerate(blocks):
+            contiguous(blk["qkv"], "qkv")
+            contiguous(blk["out"], "out")
+            B_ = V.block[i]
+            _copy_struct(B_.ln1, blk["ln1"])
+            _copy_struct(B_.ln2, blk["ln2"])
+            _copy_struct(B_.qkv, blk["qkv"][0])
+            B_.qkv.k = dim
+            _copy_struct(B_.out, blk["out"][0])
+            B_.out.n = dim
+            B_.out.b = blk["out_bias"][0]
+            _copy_struct(B_.ff1, blk["ff1"])
+            _copy_struct(B_.ff2, blk["ff2"])
+        _copy_struct(V.head_ln, hln)
+        _copy_struct(V.head_fc, hfc)
+        self.desc = V
+
+
 class PackedLane:
     """Lane_Encoder (Lane_encoder.py:7-33) descriptor."""
 
@@ -377,6 +452,18 @@ def cnn_forward(cnn: PackedCnn, maps: torch.Tensor, input_affine: bool = True):
     out = torch.empty(B, N.n_out, dtype=torch.float32, device=maps.device)
     lib = _lib.load()
     _lib.check(lib.mmt_cnn_forward(C.byref(N), _ptr(maps), B, _ptr(out), None, _stream()), "mmt_cnn_forward")
+    return out
+
+
+def vit_forward(vit: PackedVit, maps: torch.Tensor, input_affine: bool = True):
+    """ViT.forward: maps (B,C,S,S) -> (B,num_classes); input_affine applies map*2-1 inside the kernel."""
+    V = vit.desc
+    V.input_affine = int(bool(input_affine))
+    _chk(maps, "map", (None, V.channels, V.image, V.image))
+    B = maps.shape[0]
+    out = torch.empty(B, V.n_out, dtype=torch.float32, device=maps.device)
+    lib = _lib.load()
+    _lib.check(lib.mmt_vit_forward(C.byref(V), _ptr(maps), B, _ptr(out), _stream()), "mmt_vit_forward")
     return out
 
 

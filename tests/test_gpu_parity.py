@@ -209,3 +209,31 @@ def test_error_paths():
         model.predict(x, x_st[:0].contiguous(), None, None, None, 12)               # empty batch
     with pytest.raises(MmtError):
         model.predict(x, x_st, None, None, None, 64)                                # horizon beyond the kernel's cap
+
+
+def test_vit_map_encoder_matches_cpu_restatement():
+    """ViT parity is UNPINNED against the reference (vit_pytorch 0.33.2 is not available offline): the check is
+    against oracle/reference_form.MapViT, a restatement of that package's published architecture."""
+    from oracle import reference_form as rf
+    dev = _dev()
+    hp = make_hyperparams("map_vit", history=8, horizon=12)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=4)
+    batch = make_batch(6, 8, 12, seed=5, with_map=True)
+    x, x_st, y, y_st, lanes, maps = _to(batch, dev)
+    vit = reg.model_dict["VEHICLE/map_encoder"]
+    got = vit.forward_raw(maps).cpu().numpy()
+    ref = rf.ReferenceFormModel(hp)
+    apply_recipe(ref.m, seed=4)
+    ref.m.eval()
+    with torch.no_grad():
+        want = ref.m["VEHICLE/map_encoder"](torch.from_numpy(batch["map"]) * 2.0 - 1.0).numpy()
+        hist_want, _ = ref.predict(torch.from_numpy(batch["x"]), torch.from_numpy(batch["x_st"]), None,
+                                   torch.from_numpy(batch["map"]), 12)
+    assert rel_err(got, want) <= TOL
+    # drop-in call form: forward(map*2-1)
+    got2 = vit((maps * 2.0 - 1.0).contiguous()).cpu().numpy()
+    assert rel_err(got2, want) <= TOL
+    hist, _ = model.predict(x, x_st, None, None, maps, 12)
+    node = batch["x"][:, -1, 0:2][:, None, :]
+    assert rel_err((hist.cpu().numpy() - node) / 80.0, (hist_want.numpy() - node) / 80.0) <= TOL
