@@ -127,6 +127,43 @@ typedef struct {
   mmt_linear head_fc;
 } mmt_vit;
 
+/* ---- training-step building blocks (train.py:218-256, mgcvae.py:559-627) ------------------------ */
+/* C[m][n] (+)= epi( sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] ) ;  epi: +bias[n], +addend[m*ld_add + n], relu,
+ * zero where mask[m*ld_mask + n] <= 0.  One kernel serves X W^T (forward), dY W (input grads), dY^T X (weight grads). */
+typedef struct {
+  const float *A;
+  int64_t sam, sak;
+  const float *B;
+  int64_t sbk, sbn;
+  float *C;
+  int64_t ldc;
+  int32_t M, N, K;
+  const float *bias, *addend;
+  int64_t ld_add;
+  const float *mask;
+  int64_t ld_mask;
+  int32_t relu, accumulate;
+} mmt_gemm_args;
+
+/* short-sequence multi-head attention with explicit (batch stride, row stride) per operand, in floats */
+typedef struct {
+  const float *q, *k, *v;
+  float *o, *probs;                 /* probs (B,H,Lq,Lk) stash, zero for masked keys */
+  const uint8_t *pad;               /* (B,Lk) key padding or NULL */
+  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int32_t B, H, Lq, Lk, dh, causal, causal_offset;
+  float scale;
+} mmt_attn_args;
+
+typedef struct {
+  float *param;
+  const float *grad;
+  float *exp_avg, *exp_avg_sq;
+  int64_t numel;
+  float lr_scale;                   /* per-group multiplier on state[1] (map_encoder group: 2.0, train.py:218-219) */
+  int32_t pad_;
+} mmt_adamw_tensor;
+
 const char *mmt_last_error(void);
 int mmt_version(void);
 
@@ -169,6 +206,26 @@ int mmt_lane_forward(const mmt_lane *lane, const float *lanes, int n_rows, float
  * or NULL; ade/fde (B) out or NULL; loss_sum (1) accumulates sum_b mean_t ||.||2 (caller zeroes). */
 int mmt_finalize(const float *pred_st, const float *node_pos, const float *gt, int metric_in_metres,
                  int B, int ph, float *pred_m, float *ade, float *fde, float *loss_sum, void *stream);
+
+/* ---- training ops: all whole-batch, asynchronous on `stream`, graph-capturable ------------------------------------ */
+int mmt_gemm(const mmt_gemm_args *g, void *stream);
+/* out[n] (+)= sum_m a[m*lda+n] * (b ? b[m*ldb+n] : 1), rows with mask[m*ldm+n] <= 0 skipped: bias / LayerNorm grads */
+int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,
+               float *out, int accumulate, void *stream);
+/* y = [relu](LayerNorm(x + res)) with eps 1e-5; stashes xhat (M,N), rstd (M)   (nn.LayerNorm; MLP.py:13-16) */
+int mmt_layernorm_fwd(const float *x, const float *res, int M, int N, const float *g, const float *b, int relu,
+                      float *y, float *xhat, float *rstd, void *stream);
+int mmt_layernorm_bwd(const float *dy, const float *xhat, const float *rstd, const float *g, const float *y_relu,
+                      int M, int N, float *dx, int accumulate, float *dy_masked, void *stream);
+int mmt_attention_fwd(const mmt_attn_args *a, void *stream);
+/* dq (=), dk += , dv += ; dk/dv share strides (dk_bs, dk_rs) */
+int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long do_bs, long do_rs, float *dq, long dq_bs,
+                      long dq_rs, float *dk, float *dv, long dk_bs, long dk_rs, void *stream);
+/* pos [ph][B][2], y [B][ph][2]: dpos = d/dpos mean_b mean_t ||pos-y||_2; loss_sum (1) += that mean (may be NULL) */
+int mmt_l2_loss_bwd(const float *pos, const float *y, int B, int ph, float *dpos, float *loss_sum, void *stream);
+/* clip_grad_value_(clip) + torch.optim.AdamW over a device-resident table; state_dev = {step, lr} floats on the device */
+int mmt_adamw_multi(const mmt_adamw_tensor *table_dev, int ntensors, const float *state_dev, float beta1, float beta2,
+                    float eps, float weight_decay, float clip, float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

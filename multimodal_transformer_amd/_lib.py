@@ -77,6 +77,24 @@ class Vit(C.Structure):
                 ("block", VitBlock * MMT_MAX_LAYERS), ("head_ln", Norm), ("head_fc", Linear)]
 
 
+class GemmArgs(C.Structure):
+    _fields_ = [("A", fptr), ("sam", C.c_int64), ("sak", C.c_int64), ("B", fptr), ("sbk", C.c_int64),
+                ("sbn", C.c_int64), ("C", fptr), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("bias", fptr), ("addend", fptr), ("ld_add", C.c_int64), ("mask", fptr),
+                ("ld_mask", C.c_int64), ("relu", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", fptr), ("k", fptr), ("v", fptr), ("o", fptr), ("probs", fptr), ("pad", fptr)] + \
+               [(n, C.c_int64) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs")] + \
+               [(n, C.c_int32) for n in ("B", "H", "Lq", "Lk", "dh", "causal", "causal_offset")] + [("scale", C.c_float)]
+
+
+class AdamwTensor(C.Structure):
+    _fields_ = [("param", fptr), ("grad", fptr), ("exp_avg", fptr), ("exp_avg_sq", fptr), ("numel", C.c_int64),
+                ("lr_scale", C.c_float), ("pad_", C.c_int32)]
+
+
 # symbol -> (restype, argtypes); tests check that the library exports exactly these
 SIGNATURES = {
     "mmt_last_error": (C.c_char_p, []),
@@ -91,6 +109,16 @@ SIGNATURES = {
     "mmt_cnn_forward": (C.c_int, [C.POINTER(Cnn), fptr, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_vit_forward": (C.c_int, [C.POINTER(Vit), fptr, C.c_int, fptr, C.c_void_p]),
     "mmt_lane_forward": (C.c_int, [C.POINTER(Lane), fptr, C.c_int, fptr, C.c_void_p]),
+    "mmt_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "mmt_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, fptr, C.c_int, C.c_void_p]),
+    "mmt_layernorm_fwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_int, fptr, fptr, fptr, C.c_void_p]),
+    "mmt_layernorm_bwd": (C.c_int, [fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, C.c_void_p]),
+    "mmt_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "mmt_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), fptr, C.c_long, C.c_long, fptr, C.c_long, C.c_long, fptr, fptr,
+                                    C.c_long, C.c_long, C.c_void_p]),
+    "mmt_l2_loss_bwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_adamw_multi": (C.c_int, [fptr, C.c_int, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_void_p]),
     "mmt_finalize": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_void_p]),
 }
 

@@ -1,0 +1,417 @@
+// Training-step building blocks for gfx950: whole-batch fp32 kernels that the host
+// orchestration (multimodal_transformer_amd/training.py) chains into forward-with-stash, the reverse-time
+// backward sweep through the KV-cached autoregressive decoder, deferred weight-gradient GEMMs over all
+// (step, agent) rows, and one fused clip-by-value + AdamW update.  Everything is launched on the caller's
+// stream and is capturable in a HIP graph (no allocation, no host sync).
+//
+//   mmt_gemm            C = epilogue(A x B)   arbitrary strides: forward (X W^T), input grads (dY W) and
+//                       weight grads (dY^T X) share one fp32-MFMA kernel (v_mfma_f32_16x16x4_f32)
+//   mmt_colsum          bias / LayerNorm parameter gradients: sum_m a[m][n] (* b[m][n])
+//   mmt_layernorm_fwd/bwd   residual add + LayerNorm (+ReLU), stashing xhat / rstd
+//   mmt_attention_fwd/bwd   short-sequence multi-head attention with arbitrary strides: encoder (causal, T x T),
+//                       decoder self-attention on the KV cache (1 x s), cross-attention (1 x T, key padding)
+//   mmt_l2_loss_bwd     d/dpos of mean_b mean_t ||pos - y||_2                      (mgcvae.py:614-620)
+//   mmt_adamw_multi     clip_grad_value_ + AdamW over a table of tensors            (train.py:218-253)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <stdint.h>
+#include "../../include/mmt_amd.h"
+
+int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ GEMM
+constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;   // LDS row stride 20 floats (16-B aligned rows)
+
+__global__ __launch_bounds__(256) void mmt_gemm_kernel(mmt_gemm_args g) {
+  __shared__ __align__(16) float As[GBM * GLD];
+  __shared__ __align__(16) float Bs[GBN * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;     // each wave: 32 x 32 = 2 x 2 MFMA tiles
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < g.K; k0 += GBK) {
+    // stage A[m0:m0+64, k0:k0+16] and B[k0:k0+16, n0:n0+64] (as Bs[n][k]); pick the thread->element map that
+    // walks the unit-stride dimension of each operand
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m, k;
+      if (g.sak == 1) {
+        k = tid & 15;
+        m = (tid >> 4) + 16 * i;
+      } else {
+        m = tid & 63;
+        k = (tid >> 6) + 4 * i;
+      }
+      const int gm = m0 + m, gk = k0 + k;
+      As[m * GLD + k] = (gm < g.M && gk < g.K) ? g.A[(size_t)gm * g.sam + (size_t)gk * g.sak] : 0.f;
+      int n, kb;
+      if (g.sbk == 1) {
+        kb = tid & 15;
+        n = (tid >> 4) + 16 * i;
+      } else {
+        n = tid & 63;
+        kb = (tid >> 6) + 4 * i;
+      }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[n * GLD + kb] = (gn < g.N && gkb < g.K) ? g.B[(size_t)gkb * g.sbk + (size_t)gn * g.sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 16) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const f32x4 *>(&As[(wm + 16 * i + (lane & 15)) * GLD + kk + 4 * (lane >> 4)]);
+        b[i] = *reinterpret_cast<const f32x4 *>(&Bs[(wn + 16 * i + (lane & 15)) * GLD + kk + 4 * (lane >> 4)]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn + 16 * j + (lane & 15);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+        float *c = g.C + (size_t)m * g.ldc + n;
+        *c = g.accumulate ? (*c + v) : v;
+      }
+    }
+}
+
+// out[n] (+)= sum_m a[m][n] * (b ? b[m][n] : 1) [only where mask[m][n] > 0]; deterministic order
+__global__ __launch_bounds__(256) void mmt_colsum_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                         const float *__restrict__ mask, int M, int N, long lda,
+                                                         long ldb, long ldm, float *__restrict__ out, int accumulate) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < N)
+    for (int m = rl; m < M; m += 4) {
+      float v = a[(size_t)m * lda + c];
+      if (b) v *= b[(size_t)m * ldb + c];
+      if (mask && !(mask[(size_t)m * ldm + c] > 0.f)) v = 0.f;
+      s += v;
+    }
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// y = [relu](LN(x + res) * g + b); stashes xhat (M,N) and rstd (M).  One wave per row.
+__global__ __launch_bounds__(256) void mmt_ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                         int M, int N, const float *__restrict__ g,
+                                                         const float *__restrict__ b, int relu, float *__restrict__ y,
+                                                         float *__restrict__ xhat, float *__restrict__ rstd_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float *xr = x + (size_t)row * N, *rr = res ? res + (size_t)row * N : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mu = s / (float)N;
+  float v = 0.f;
+  for (int c = lane; c < N; c += 64) {
+    const float d = xr[c] + (rr ? rr[c] : 0.f) - mu;
+    v += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const float rstd = 1.0f / sqrtf(v / (float)N + 1e-5f);
+  for (int c = lane; c < N; c += 64) {
+    const float h = (xr[c] + (rr ? rr[c] : 0.f) - mu) * rstd;
+    float o = h * g[c] + b[c];
+    if (relu) o = fmaxf(o, 0.f);
+    y[(size_t)row * N + c] = o;
+    xhat[(size_t)row * N + c] = h;
+  }
+  if (lane == 0) rstd_out[row] = rstd;
+}
+
+// dx (+)= rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * g [masked where y <= 0 if relu];
+// the masked dy is written to dy_masked (may alias dy) for the deferred parameter-gradient reduction.
+__global__ __launch_bounds__(256) void mmt_ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ xhat,
+                                                         const float *__restrict__ rstd, const float *__restrict__ g,
+                                                         const float *__restrict__ y_relu, int M, int N,
+                                                         float *__restrict__ dx, int accumulate,
+                                                         float *__restrict__ dy_masked) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const size_t o = (size_t)row * N;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < N; c += 64) {
+    float d = dy[o + c];
+    if (y_relu && !(y_relu[o + c] > 0.f)) d = 0.f;
+    if (dy_masked) dy_masked[o + c] = d;
+    const float dg = d * g[c];
+    s1 += dg;
+    s2 += dg * xhat[o + c];
+  }
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) {
+    s1 += __shfl_xor(s1, k, 64);
+    s2 += __shfl_xor(s2, k, 64);
+  }
+  const float m1 = s1 / (float)N, m2 = s2 / (float)N, rs = rstd[row];
+  for (int c = lane; c < N; c += 64) {
+    float d = dy_masked ? dy_masked[o + c] : dy[o + c];
+    if (!dy_masked && y_relu && !(y_relu[o + c] > 0.f)) d = 0.f;
+    const float v = rs * (d * g[c] - m1 - xhat[o + c] * m2);
+    dx[o + c] = accumulate ? dx[o + c] + v : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// One thread per (batch, head, query).  Keys 0..nk-1 with nk = causal ? min(i + 1 + causal_offset, Lk) : Lk;
+// key j masked when pad[b*Lk + j].  All operands addressed by (batch stride, row stride) in floats.
+__global__ void mmt_attn_fwd_kernel(mmt_attn_args a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * a.H * a.Lq) return;
+  const int i = idx % a.Lq, h = (idx / a.Lq) % a.H, b = idx / (a.Lq * a.H);
+  const int dh = a.dh;
+  const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * dh;
+  const float *K = a.k + (size_t)b * a.k_bs + h * dh, *V = a.v + (size_t)b * a.v_bs + h * dh;
+  const int nk = a.causal ? min(i + 1 + a.causal_offset, a.Lk) : a.Lk;
+  float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
+  float qv[64], o[64];
+  for (int c = 0; c < dh; ++c) {
+    qv[c] = q[c];
+    o[c] = 0.f;
+  }
+  float mx = -INFINITY;
+  for (int j = 0; j < nk; ++j) {
+    float s = -INFINITY;
+    if (!(a.pad && a.pad[(size_t)b * a.Lk + j])) {
+      const float *kj = K + (size_t)j * a.k_rs;
+      float acc = 0.f;
+      for (int c = 0; c < dh; ++c) acc = fmaf(qv[c], kj[c], acc);
+      s = acc * a.scale;
+    }
+    P[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < nk; ++j) {
+    const float e = mx > -INFINITY ? expf(P[j] - mx) : 0.f;
+    P[j] = e;
+    sum += e;
+  }
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+  for (int j = 0; j < a.Lk; ++j) {
+    const float p = j < nk ? P[j] * inv : 0.f;
+    P[j] = p;
+    if (p > 0.f) {
+      const float *vj = V + (size_t)j * a.v_rs;
+      for (int c = 0; c < dh; ++c) o[c] = fmaf(p, vj[c], o[c]);
+    }
+  }
+  float *out = a.o + (size_t)b * a.o_bs + (size_t)i * a.o_rs + h * dh;
+  for (int c = 0; c < dh; ++c) out[c] = o[c];
+}
+
+// One thread per (batch, head): dq (=) , dk += , dv +=  from dO and the stashed probabilities.
+__global__ void mmt_attn_bwd_kernel(mmt_attn_args a, const float *__restrict__ dO, long do_bs, long do_rs,
+                                    float *__restrict__ dq, long dq_bs, long dq_rs, float *__restrict__ dk,
+                                    float *__restrict__ dv, long dk_bs, long dk_rs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * a.H) return;
+  const int h = idx % a.H, b = idx / a.H;
+  const int dh = a.dh;
+  const float *K = a.k + (size_t)b * a.k_bs + h * dh, *V = a.v + (size_t)b * a.v_bs + h * dh;
+  float *dK = dk + (size_t)b * dk_bs + h * dh, *dV = dv + (size_t)b * dk_bs + h * dh;
+  for (int i = 0; i < a.Lq; ++i) {
+    const float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
+    const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * dh;
+    const float *g = dO + (size_t)b * do_bs + (size_t)i * do_rs + h * dh;
+    float *dqi = dq + (size_t)b * dq_bs + (size_t)i * dq_rs + h * dh;
+    float gv[64], qv[64], dqa[64];
+    for (int c = 0; c < dh; ++c) {
+      gv[c] = g[c];
+      qv[c] = q[c];
+      dqa[c] = 0.f;
+    }
+    float dP[32];
+    float dot = 0.f;
+    for (int j = 0; j < a.Lk; ++j) {
+      float t = 0.f;
+      if (P[j] > 0.f) {
+        const float *vj = V + (size_t)j * a.v_rs;
+        for (int c = 0; c < dh; ++c) t = fmaf(gv[c], vj[c], t);
+      }
+      dP[j] = t;
+      dot = fmaf(P[j], t, dot);
+    }
+    for (int j = 0; j < a.Lk; ++j) {
+      const float p = P[j];
+      if (!(p > 0.f)) continue;
+      const float ds = p * (dP[j] - dot) * a.scale;
+      const float *kj = K + (size_t)j * a.k_rs;
+      float *dkj = dK + (size_t)j * dk_rs, *dvj = dV + (size_t)j * dk_rs;
+      for (int c = 0; c < dh; ++c) {
+        dqa[c] = fmaf(ds, kj[c], dqa[c]);
+        dkj[c] = fmaf(ds, qv[c], dkj[c]);
+        dvj[c] = fmaf(p, gv[c], dvj[c]);
+      }
+    }
+    for (int c = 0; c < dh; ++c) dqi[c] = dqa[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ loss / optimizer
+// dpos[t][b][:] = (pos - y) / ||pos - y|| / (B * ph)   with pos laid out [ph][B][2], y laid out [B][ph][2]
+__global__ void mmt_l2_loss_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ y, int B, int ph,
+                                       float *__restrict__ dpos, float *__restrict__ loss_sum) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  float contrib = 0.f;
+  if (idx < B * ph) {
+    const int b = idx % B, t = idx / B;
+    const float dx = pos[(size_t)idx * 2] - y[((size_t)b * ph + t) * 2];
+    const float dy = pos[(size_t)idx * 2 + 1] - y[((size_t)b * ph + t) * 2 + 1];
+    const float n = sqrtf(dx * dx + dy * dy);
+    const float w = n > 0.f ? 1.0f / (n * (float)B * (float)ph) : 0.f;
+    dpos[(size_t)idx * 2] = dx * w;
+    dpos[(size_t)idx * 2 + 1] = dy * w;
+    contrib = n / ((float)B * (float)ph);
+  }
+  if (loss_sum) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, contrib);
+  }
+}
+
+// state[0] = step count (float), state[1] = learning rate of group 0 (both live on the device so that a captured
+// graph stays valid while the host scheduler changes them).
+__global__ void mmt_adamw_kernel(const mmt_adamw_tensor *__restrict__ table, int ntensors, const float *__restrict__ state,
+                                 float beta1, float beta2, float eps, float weight_decay, float clip, float grad_scale) {
+  const int t = blockIdx.y;
+  if (t >= ntensors) return;
+  const mmt_adamw_tensor T = table[t];
+  const float step = state[0], lr = state[1] * T.lr_scale;
+  const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)T.numel; i += (size_t)gridDim.x * blockDim.x) {
+    float g = T.grad[i] * grad_scale;
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);            // nn.utils.clip_grad_value_
+    float p = T.param[i];
+    p *= 1.0f - lr * weight_decay;                                // decoupled weight decay
+    const float m = beta1 * T.exp_avg[i] + (1.0f - beta1) * g;
+    const float v = beta2 * T.exp_avg_sq[i] + (1.0f - beta2) * g * g;
+    T.exp_avg[i] = m;
+    T.exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+    p -= (lr / bc1) * (m / denom);
+    T.param[i] = p;
+  }
+}
+
+}  // namespace
+
+static int launch_ok(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return MMT_OK;
+}
+
+extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
+  if (!g || !g->A || !g->B || !g->C) return mmt_set_error(MMT_EINVAL, "mmt_gemm: null pointer");
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0) return mmt_set_error(MMT_EINVAL, "mmt_gemm: empty problem %dx%dx%d", g->M, g->N, g->K);
+  dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM);
+  hipLaunchKernelGGL(mmt_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *g);
+  return launch_ok("mmt_gemm");
+}
+
+extern "C" int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,
+                          float *out, int accumulate, void *stream) {
+  if (!a || !out || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_colsum: bad arguments");
+  hipLaunchKernelGGL(mmt_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, b, mask, M, N, lda, ldb,
+                     ldm, out, accumulate);
+  return launch_ok("mmt_colsum");
+}
+
+extern "C" int mmt_layernorm_fwd(const float *x, const float *res, int M, int N, const float *g, const float *b, int relu,
+                                 float *y, float *xhat, float *rstd, void *stream) {
+  if (!x || !g || !b || !y || !xhat || !rstd || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_layernorm_fwd: bad arguments");
+  hipLaunchKernelGGL(mmt_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, M, N, g, b, relu, y, xhat,
+                     rstd);
+  return launch_ok("mmt_layernorm_fwd");
+}
+
+extern "C" int mmt_layernorm_bwd(const float *dy, const float *xhat, const float *rstd, const float *g, const float *y_relu,
+                                 int M, int N, float *dx, int accumulate, float *dy_masked, void *stream) {
+  if (!dy || !xhat || !rstd || !g || !dx || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_layernorm_bwd: bad arguments");
+  hipLaunchKernelGGL(mmt_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, g, y_relu, M, N,
+                     dx, accumulate, dy_masked);
+  return launch_ok("mmt_layernorm_bwd");
+}
+
+static int check_attn(const mmt_attn_args *a, const char *who) {
+  if (!a || !a->q || !a->k || !a->v || !a->probs) return mmt_set_error(MMT_EINVAL, "%s: null pointer", who);
+  if (a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->Lk > 32 || a->dh <= 0 || a->dh > 64)
+    return mmt_set_error(MMT_EINVAL, "%s: need B,H,Lq > 0, 1 <= Lk <= 32, 1 <= dh <= 64", who);
+  return MMT_OK;
+}
+
+extern "C" int mmt_attention_fwd(const mmt_attn_args *a, void *stream) {
+  if (int rc = check_attn(a, "mmt_attention_fwd")) return rc;
+  if (!a->o) return mmt_set_error(MMT_EINVAL, "mmt_attention_fwd: null output");
+  const int total = a->B * a->H * a->Lq;
+  hipLaunchKernelGGL(mmt_attn_fwd_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
+  return launch_ok("mmt_attention_fwd");
+}
+
+extern "C" int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long do_bs, long do_rs, float *dq, long dq_bs,
+                                 long dq_rs, float *dk, float *dv, long dk_bs, long dk_rs, void *stream) {
+  if (int rc = check_attn(a, "mmt_attention_bwd")) return rc;
+  if (!d_o || !dq || !dk || !dv) return mmt_set_error(MMT_EINVAL, "mmt_attention_bwd: null gradient pointer");
+  const int total = a->B * a->H;
+  hipLaunchKernelGGL(mmt_attn_bwd_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a, d_o, do_bs, do_rs, dq,
+                     dq_bs, dq_rs, dk, dv, dk_bs, dk_rs);
+  return launch_ok("mmt_attention_bwd");
+}
+
+extern "C" int mmt_l2_loss_bwd(const float *pos, const float *y, int B, int ph, float *dpos, float *loss_sum, void *stream) {
+  if (!pos || !y || !dpos || B <= 0 || ph <= 0) return mmt_set_error(MMT_EINVAL, "mmt_l2_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(mmt_l2_loss_bwd_kernel, dim3((B * ph + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, y, B, ph, dpos,
+                     loss_sum);
+  return launch_ok("mmt_l2_loss_bwd");
+}
+
+extern "C" int mmt_adamw_multi(const mmt_adamw_tensor *table_dev, int ntensors, const float *state_dev, float beta1, float beta2,
+                               float eps, float weight_decay, float clip, float grad_scale, void *stream) {
+  if (!table_dev || !state_dev || ntensors <= 0) return mmt_set_error(MMT_EINVAL, "mmt_adamw_multi: bad arguments");
+  hipLaunchKernelGGL(mmt_adamw_kernel, dim3(64, ntensors), dim3(256), 0, (hipStream_t)stream, table_dev, ntensors, state_dev,
+                     beta1, beta2, eps, weight_decay, clip, grad_scale);
+  return launch_ok("mmt_adamw_multi");
+}

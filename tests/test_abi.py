@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     hdr = open(os.path.join(ROOT, "include", "mmt_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(mmt_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(mmt_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_header_and_binding_agree():
