@@ -227,6 +227,11 @@ int mmt_l2_loss_bwd(const float *pos, const float *y, int B, int ph, float *dpos
 int mmt_adamw_multi(const mmt_adamw_tensor *table_dev, int ntensors, const float *state_dev, float beta1, float beta2,
                     float eps, float weight_decay, float clip, float grad_scale, void *stream);
 
+/* x0 = nan_to_num(x_st, nan=0) (Transformer_model.py:47); pad[row] = isnan(x_st[row][1]) (model_utils.py:148-151) */
+int mmt_history_prepare(const float *x_st, int rows, int n_in, float *x0, uint8_t *pad, void *stream);
+/* state[0] += 1 (step count), state[1] *= gamma: ExponentialLR stepped once per batch (train.py:226-227,253-256) */
+int mmt_lr_step(float *state_dev, float gamma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

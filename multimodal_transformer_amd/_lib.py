@@ -119,6 +119,8 @@ SIGNATURES = {
     "mmt_l2_loss_bwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_adamw_multi": (C.c_int, [fptr, C.c_int, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_void_p]),
+    "mmt_history_prepare": (C.c_int, [fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_lr_step": (C.c_int, [fptr, C.c_float, C.c_void_p]),
     "mmt_finalize": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_void_p]),
 }
 

@@ -1,0 +1,228 @@
+"""Tensor-view front end of the training-step kernels (include/mmt_amd.h, "training ops").
+
+Each function takes torch *views* (device memory, fp32), derives raw pointers and element strides from
+them and launches one HIP kernel on torch's current stream.  Nothing here computes with torch: a CPU
+tensor raises.  `training.py` is written purely against this module's eight entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MmtError
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise MmtError(f"{name}: tensor is on {t.device}; the training kernels need device memory (no CPU fallback)")
+    if t.dtype != dtype:
+        raise MmtError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    return t
+
+
+def _rows(t, name):
+    """(M,N) view with unit column stride -> (ptr, ld)."""
+    _dev(t, name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise MmtError(f"{name}: expected a 2-D view with unit column stride, got shape {tuple(t.shape)} "
+                       f"strides {t.stride()}")
+    return t.stride(0)
+
+
+def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False):
+    """Cm (+)= epi(A @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
+    epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0."""
+    _dev(A, "A"), _dev(B, "B")
+    M, K = A.shape
+    K2, N = B.shape
+    if K2 != K or tuple(Cm.shape) != (M, N):
+        raise MmtError(f"gemm: shapes A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)} do not agree")
+    g = _lib.GemmArgs()
+    g.A, g.sam, g.sak = A.data_ptr(), A.stride(0), A.stride(1)
+    g.B, g.sbk, g.sbn = B.data_ptr(), B.stride(0), B.stride(1)
+    g.C, g.ldc = Cm.data_ptr(), _rows(Cm, "C")
+    g.M, g.N, g.K = M, N, K
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise MmtError("gemm: bias must be a contiguous vector of N elements")
+        g.bias = bias.data_ptr()
+    if addend is not None:
+        if tuple(addend.shape) != (M, N):
+            raise MmtError(f"gemm: addend shape {tuple(addend.shape)} != {(M, N)}")
+        g.addend, g.ld_add = addend.data_ptr(), _rows(addend, "addend")
+    if mask is not None:
+        if tuple(mask.shape) != (M, N):
+            raise MmtError(f"gemm: mask shape {tuple(mask.shape)} != {(M, N)}")
+        g.mask, g.ld_mask = mask.data_ptr(), _rows(mask, "mask")
+    g.relu, g.accumulate = int(bool(relu)), int(bool(accumulate))
+    lib = _lib.load()
+    _lib.check(lib.mmt_gemm(C.byref(g), _stream()), "mmt_gemm")
+
+
+def colsum(a, out, b=None, mask=None, accumulate=False):
+    """out[n] (+)= sum_m a[m,n] * b[m,n] (b optional) over rows where mask[m,n] > 0 (mask optional)."""
+    lda = _rows(a, "a")
+    M, N = a.shape
+    ldb = _rows(b, "b") if b is not None else 0
+    ldm = _rows(mask, "mask") if mask is not None else 0
+    _dev(out, "out")
+    if out.numel() != N or not out.is_contiguous():
+        raise MmtError("colsum: out must be a contiguous vector of N elements")
+    lib = _lib.load()
+    _lib.check(lib.mmt_colsum(_p(a), _p(b), _p(mask), M, N, lda, ldb, ldm, _p(out), int(bool(accumulate)), _stream()),
+               "mmt_colsum")
+
+
+def _contig2(t, name, shape=None):
+    _dev(t, name)
+    if not t.is_contiguous() or (shape is not None and tuple(t.shape) != tuple(shape)):
+        raise MmtError(f"{name}: expected a contiguous tensor of shape {shape}, got {tuple(t.shape)} {t.stride()}")
+    return t
+
+
+def layernorm_fwd(x, res, g, b, y, xhat, rstd, relu=False):
+    """y = [relu](LayerNorm(x + res) * g + b), eps 1e-5; stashes xhat (M,N) and rstd (M)."""
+    M, N = x.shape
+    for t, n in ((x, "x"), (y, "y"), (xhat, "xhat")):
+        _contig2(t, n, (M, N))
+    if res is not None:
+        _contig2(res, "res", (M, N))
+    _contig2(rstd, "rstd", (M,))
+    lib = _lib.load()
+    _lib.check(lib.mmt_layernorm_fwd(_p(x), _p(res), M, N, _p(_dev(g, "g")), _p(_dev(b, "b")), int(bool(relu)), _p(y),
+                                     _p(xhat), _p(rstd), _stream()), "mmt_layernorm_fwd")
+
+
+def layernorm_bwd(dy, xhat, rstd, g, dx, y_relu=None, dy_masked=None, accumulate=False):
+    """dx (+)= LayerNorm backward of dy (zeroed where y_relu <= 0); the masked dy goes to dy_masked."""
+    M, N = dy.shape
+    for t, n in ((dy, "dy"), (xhat, "xhat"), (dx, "dx")):
+        _contig2(t, n, (M, N))
+    _contig2(rstd, "rstd", (M,))
+    if y_relu is not None:
+        _contig2(y_relu, "y_relu", (M, N))
+    if dy_masked is not None:
+        _contig2(dy_masked, "dy_masked", (M, N))
+    lib = _lib.load()
+    _lib.check(lib.mmt_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(_dev(g, "g")), _p(y_relu), M, N, _p(dx),
+                                     int(bool(accumulate)), _p(dy_masked), _stream()), "mmt_layernorm_bwd")
+
+
+def _bld(t, name, B, L, d):
+    _dev(t, name)
+    if tuple(t.shape) != (B, L, d) or t.stride(2) != 1:
+        raise MmtError(f"{name}: expected a (B,L,d)=({B},{L},{d}) view with unit feature stride, got "
+                       f"{tuple(t.shape)} {t.stride()}")
+    return t.stride(0), t.stride(1)
+
+
+def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None):
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    a = _lib.AttnArgs()
+    a.q_bs, a.q_rs = _bld(q, "q", B, Lq, d)
+    a.k_bs, a.k_rs = _bld(k, "k", B, Lk, d)
+    a.v_bs, a.v_rs = _bld(v, "v", B, Lk, d)
+    a.q, a.k, a.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    if o is not None:
+        a.o_bs, a.o_rs = _bld(o, "o", B, Lq, d)
+        a.o = o.data_ptr()
+    _dev(probs, "probs")
+    if not probs.is_contiguous() or probs.numel() != B * nhead * Lq * Lk:
+        raise MmtError(f"probs: expected {B * nhead * Lq * Lk} contiguous floats")
+    a.probs = probs.data_ptr()
+    if pad is not None:
+        _dev(pad, "pad", torch.uint8)
+        if tuple(pad.shape) != (B, Lk) or not pad.is_contiguous():
+            raise MmtError(f"pad: expected a contiguous (B,Lk)=({B},{Lk}) uint8 mask")
+        a.pad = pad.data_ptr()
+    if d % nhead:
+        raise MmtError("attention: d_model is not divisible by nhead")
+    a.B, a.H, a.Lq, a.Lk, a.dh = B, nhead, Lq, Lk, d // nhead
+    a.causal, a.causal_offset, a.scale = int(bool(causal)), int(causal_offset), float(scale)
+    return a
+
+
+def attention_fwd(q, k, v, o, probs, nhead, scale, pad=None, causal=False, causal_offset=0):
+    """o = softmax(scale * q k^T + masks) v per head; q,o (B,Lq,d) and k,v (B,Lk,d) strided views; the
+    probabilities (B,H,Lq,Lk) are stashed (zero at masked keys)."""
+    a = _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=o)
+    lib = _lib.load()
+    _lib.check(lib.mmt_attention_fwd(C.byref(a), _stream()), "mmt_attention_fwd")
+
+
+def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale):
+    """dq (=), dk (+=), dv (+=) from d_o and the stashed probabilities; dk and dv must share strides."""
+    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale)
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    do_bs, do_rs = _bld(d_o, "d_o", B, Lq, d)
+    dq_bs, dq_rs = _bld(dq, "dq", B, Lq, d)
+    dk_bs, dk_rs = _bld(dk, "dk", B, Lk, d)
+    if _bld(dv, "dv", B, Lk, d) != (dk_bs, dk_rs):
+        raise MmtError("attention_bwd: dk and dv must share strides")
+    lib = _lib.load()
+    _lib.check(lib.mmt_attention_bwd(C.byref(a), _p(d_o), do_bs, do_rs, _p(dq), dq_bs, dq_rs, _p(dk), _p(dv), dk_bs,
+                                     dk_rs, _stream()), "mmt_attention_bwd")
+
+
+def l2_loss_bwd(pos, y, dpos, loss_sum=None):
+    """pos (ph,B,2) step-major, y (B,ph,2): dpos = d/dpos mean_b mean_t ||pos - y||; loss_sum[0] += that mean."""
+    ph, B, _ = pos.shape
+    _contig2(pos, "pos", (ph, B, 2)), _contig2(y, "y", (B, ph, 2)), _contig2(dpos, "dpos", (ph, B, 2))
+    if loss_sum is not None:
+        _contig2(loss_sum, "loss_sum", (1,))
+    lib = _lib.load()
+    _lib.check(lib.mmt_l2_loss_bwd(_p(pos), _p(y), B, ph, _p(dpos), _p(loss_sum), _stream()), "mmt_l2_loss_bwd")
+
+
+def history_prepare(x_st, x0, pad):
+    """x0 = nan_to_num(x_st, nan=0) (Transformer_model.py:47), pad = isnan(x_st)[:, :, 1] (model_utils.py:148-151)."""
+    B, T, n = x_st.shape
+    _contig2(x_st, "x_st", (B, T, n)), _contig2(x0, "x0", (B * T, n))
+    _dev(pad, "pad", torch.uint8)
+    if tuple(pad.shape) != (B, T) or not pad.is_contiguous():
+        raise MmtError("pad: expected a contiguous (B,T) uint8 tensor")
+    lib = _lib.load()
+    _lib.check(lib.mmt_history_prepare(_p(x_st), B * T, n, _p(x0), _p(pad), _stream()), "mmt_history_prepare")
+
+
+def adamw_table(entries, device):
+    """entries: [(param, grad, exp_avg, exp_avg_sq, lr_scale)] -> device-resident mmt_adamw_tensor table."""
+    arr = (_lib.AdamwTensor * len(entries))()
+    for i, (p, g, m, v, s) in enumerate(entries):
+        for t, n in ((p, "param"), (g, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _dev(t, n)
+            if not t.is_contiguous() or t.numel() != p.numel():
+                raise MmtError(f"adamw: {n} of entry {i} is not a contiguous tensor of {p.numel()} elements")
+        arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq = (p.data_ptr(), g.data_ptr(), m.data_ptr(),
+                                                                        v.data_ptr())
+        arr[i].numel, arr[i].lr_scale = p.numel(), float(s)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device), len(entries)
+
+
+def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, grad_scale):
+    """clip_grad_value_(clip) + torch.optim.AdamW over the table; state = device [step, lr]."""
+    _dev(table, "table", torch.uint8), _contig2(state, "state", (2,))
+    lib = _lib.load()
+    _lib.check(lib.mmt_adamw_multi(_p(table), ntensors, _p(state), beta1, beta2, eps, weight_decay, clip, grad_scale,
+                                   _stream()), "mmt_adamw_multi")
+
+
+def lr_step(state, gamma):
+    """state[0] += 1 (optimizer step count), state[1] *= gamma (ExponentialLR stepped per batch, train.py:226-256)."""
+    _contig2(state, "state", (2,))
+    lib = _lib.load()
+    _lib.check(lib.mmt_lr_step(_p(state), float(gamma), _stream()), "mmt_lr_step")

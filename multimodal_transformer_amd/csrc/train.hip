@@ -336,6 +336,23 @@ __global__ void mmt_adamw_kernel(const mmt_adamw_tensor *__restrict__ table, int
   }
 }
 
+// x0 = nan_to_num(x, nan=0) over (rows, n) and pad[row] = isnan(x[row][1])
+__global__ void mmt_history_prepare_kernel(const float *__restrict__ x, int rows, int n, float *__restrict__ x0,
+                                           uint8_t *__restrict__ pad) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * n) return;
+  const float v = x[idx];
+  x0[idx] = (v != v) ? 0.f : v;
+  if (idx % n == 1) pad[idx / n] = (v != v) ? 1 : 0;
+}
+
+__global__ void mmt_lr_step_kernel(float *state, float gamma) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    state[0] += 1.0f;
+    state[1] *= gamma;
+  }
+}
+
 }  // namespace
 
 static int launch_ok(const char *what) {
@@ -414,4 +431,17 @@ extern "C" int mmt_adamw_multi(const mmt_adamw_tensor *table_dev, int ntensors, 
   hipLaunchKernelGGL(mmt_adamw_kernel, dim3(64, ntensors), dim3(256), 0, (hipStream_t)stream, table_dev, ntensors, state_dev,
                      beta1, beta2, eps, weight_decay, clip, grad_scale);
   return launch_ok("mmt_adamw_multi");
+}
+
+extern "C" int mmt_history_prepare(const float *x_st, int rows, int n_in, float *x0, uint8_t *pad, void *stream) {
+  if (!x_st || !x0 || !pad || rows <= 0 || n_in < 2) return mmt_set_error(MMT_EINVAL, "mmt_history_prepare: bad arguments");
+  hipLaunchKernelGGL(mmt_history_prepare_kernel, dim3((rows * n_in + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_st, rows,
+                     n_in, x0, pad);
+  return launch_ok("mmt_history_prepare");
+}
+
+extern "C" int mmt_lr_step(float *state_dev, float gamma, void *stream) {
+  if (!state_dev) return mmt_set_error(MMT_EINVAL, "mmt_lr_step: null state");
+  hipLaunchKernelGGL(mmt_lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, gamma);
+  return launch_ok("mmt_lr_step");
 }

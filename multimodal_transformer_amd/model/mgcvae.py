@@ -198,12 +198,21 @@ class MultimodalGenerativeCVAE(object):
 
     def train_loss(self, inputs, inputs_st, inputs_lane, lane_label, lane_t_mask, labels, labels_st, map,
                    prediction_horizon):
-        """mgcvae.py:559-627, forward value only (standardised units, dropout off).  The backward pass / fused
-        AdamW of the training step are not in this round's kernels: the returned tensor carries no graph."""
+        """mgcvae.py:559-627 -> (loss, reg_loss), standardised units, dropout-free graph.
+
+        Basic configuration: the returned scalar carries autograd -- ``loss.backward()`` runs the HIP backward
+        (training.py) and fills ``.grad`` of every parameter, so the reference's loop (train.py:244-253) works
+        unchanged; ``training.Trainer`` is the fused, graph-replayed equivalent of that whole loop body.
+        Map / lane configurations: forward value only (their context encoders have no backward kernels yet)."""
         if not self.hyperparams["autoregressive"]:
             raise MmtError("teacher-forced training (non_at_dec) is not implemented; pass autoregressive=True")
-        loss = self._loss(inputs, inputs_st, inputs_lane, labels, labels_st, map, prediction_horizon, False,
-                          ModeKeys.EVAL)
+        hp = self.hyperparams
+        if not (hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"]):
+            from ..training import train_loss_with_graph
+            loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon)
+        else:
+            loss = self._loss(inputs, inputs_st, inputs_lane, labels, labels_st, map, prediction_horizon, False,
+                              ModeKeys.EVAL)
         if self.log_writer is not None:
             self.log_writer.add_scalar("%s/%s" % (str(self.node_type), "loss"), loss, self.curr_iter)
         return loss, loss

@@ -1,0 +1,470 @@
+"""Training step of the hot path on HIP kernels (reference ``Transformer/train.py:218-256``
+driving ``mgcvae.py:559-627``): forward with stash, reverse-time backward through the KV-cached autoregressive
+decoder, deferred weight-gradient GEMMs over all (step, agent) rows, flat-bucket RCCL all-reduce, fused
+clip-by-value + AdamW + ExponentialLR.
+
+Mathematically this is the reference's autograd graph (12 full decoder passes on a growing target, BPTT through
+the fed-back positions, mgcvae.py:432-446) restated on the KV-cached recurrence: hidden state j of every decoder
+layer depends on target tokens <= j only, so its key/value are computed once (step j) and receive gradient from
+every later step s >= j; going backwards in time, dK_j / dV_j are complete exactly when step j is reached.
+
+Layout.  Encoder activations are agent-major rows (b*T + t), decoder activations are step-major rows (s*B + b) so
+that every per-step slice is contiguous and the weight gradient of each Linear is ONE GEMM over all ph*B rows.
+All buffers are allocated once per (B, T, ph); a whole step launches ~2000 small kernels and is replayed as a
+HIP graph.  Parameters are used in place (natural nn.Linear layout); gradients live in one flat buffer (the
+all-reduce bucket) whose slices are the per-parameter ``.grad`` views.
+
+Dropout: the HIP training step implements the dropout-free graph, the configuration training parity is defined
+on (the reference's dropout RNG stream is not a meaningful parity target).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _train_kernels as K
+from ._lib import MmtError
+
+
+def _t(w):
+    """nn.Linear weight (N,K) -> B operand (K,N) of ``X @ W^T``."""
+    return w.t()
+
+
+class _Stash:
+    pass
+
+
+class TrainEngine:
+    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic configuration."""
+
+    def __init__(self, model, B, T, ph, device=None):
+        hp = model.hyperparams
+        if hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"]:
+            raise MmtError("the HIP training step covers the Basic configuration (BASELINE config 2); "
+                           "map / lane context encoders have no backward kernels yet")
+        if not hp.get("autoregressive", True):
+            raise MmtError("teacher-forced training (non_at_dec) is not implemented; pass autoregressive=True")
+        self.enc = model._m("node_history_encoder")
+        self.dec = model._m("decoder/transformer_decoder")
+        self.head = model._m("decoder/MLP")
+        self.B, self.T, self.ph = int(B), int(T), int(ph)
+        if not (1 <= self.T <= 32 and 1 <= self.ph <= 32):
+            raise MmtError("training kernels support 1 <= T, ph <= 32")
+        self.device = device if device is not None else self.enc.input_fc.weight.device
+        self.d = self.enc.input_fc.weight.shape[0]
+        self.n_in = self.enc.input_fc.weight.shape[1]
+        self.H = self.enc._nhead()
+        self.dh = self.d // self.H
+        if self.dh > 64:
+            raise MmtError("head dimension > 64 is not supported by the attention kernels")
+        self.scale = 1.0 / math.sqrt(self.dh)
+        self.Le = len(self.enc.transformer_encoder.layers)
+        self.Ld = len(self.dec.transformer_decoder.layers)
+        self.f_enc = self.enc.transformer_encoder.layers[0].linear1.weight.shape[0]
+        self.f_dec = self.dec.transformer_decoder.layers[0].linear1.weight.shape[0]
+        self.n_pos = self.dec.input_fc.weight.shape[1]
+        self.n_out = self.dec.output_fc.weight.shape[0]
+        self.head_hidden = []
+        i = 0
+        while hasattr(self.head.layer_seq, f"lmlp_{i}"):
+            seq = getattr(self.head.layer_seq, f"lmlp_{i}")
+            self.head_hidden.append((seq[0], seq[1]))
+            i += 1
+        self.head_out = self.head.layer_seq.out_mlp
+        if not isinstance(self.head_out, torch.nn.Linear):
+            raise MmtError("decoder head must be a regression-mode Mlp")
+        self._collect_params(model)
+        self._alloc()
+
+    # ------------------------------------------------------------------ parameters / gradients
+    def _collect_params(self, model):
+        """(registrar key + parameter name, parameter) for every parameter that receives a gradient in the Basic
+        graph; Encoder.output_fc and Trajectory_Decoder.mix_fc never do and are skipped by the
+        optimizer exactly like torch skips ``grad is None``."""
+        nt = model.node_type
+        named = []
+        for key, mod in ((nt + "/node_history_encoder", self.enc), (nt + "/decoder/transformer_decoder", self.dec),
+                         (nt + "/decoder/MLP", self.head)):
+            for pn, p in mod.named_parameters():
+                if key.endswith("node_history_encoder") and pn.startswith("output_fc."):
+                    continue
+                if pn.startswith("mix_fc."):
+                    continue
+                named.append((f"{key}.{pn}", p))
+        self.named_params = named
+        total = 0
+        offs = []
+        for _, p in named:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise MmtError("parameters must be contiguous fp32")
+            offs.append(total)
+            total += (p.numel() + 63) & ~63
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grad_of = {}
+        self.grad_by_name = {}
+        for (name, p), o in zip(named, offs):
+            g = self.flat_grad[o:o + p.numel()].view(p.shape)
+            self.grad_of[id(p)] = g
+            self.grad_by_name[name] = g
+
+    def g(self, p):
+        return self.grad_of[id(p)]
+
+    def _buf(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def _alloc(self):
+        B, T, ph, d, H = self.B, self.T, self.ph, self.d, self.H
+        Re, S = B * T, _Stash()
+        b = self._buf
+        # static inputs
+        self.x_st = b(B, T, self.n_in)
+        self.y_st = b(B, ph, self.n_pos)
+        self.loss = b(1)
+        # encoder
+        S.x0, S.pad = b(Re, self.n_in), b(B, T, dtype=torch.uint8)
+        S.pe_enc = self.enc.pos_encoder.pe[:T].to(self.device).repeat(B, 1).contiguous()
+        S.pe_dec = self.dec.pos_encoder.pe[:ph].to(self.device).contiguous()
+        fe, fd = self.f_enc, self.f_dec
+        S.eh = [b(Re, d) for _ in range(self.Le + 1)]
+        S.eqkv = [b(Re, 3 * d) for _ in range(self.Le)]
+        S.eprobs = [b(B * H * T * T) for _ in range(self.Le)]
+        S.eatt, S.eh1 = [b(Re, d) for _ in range(self.Le)], [b(Re, d) for _ in range(self.Le)]
+        S.exhat1, S.exhat2 = [b(Re, d) for _ in range(self.Le)], [b(Re, d) for _ in range(self.Le)]
+        S.erstd1, S.erstd2 = [b(Re) for _ in range(self.Le)], [b(Re) for _ in range(self.Le)]
+        S.ef1 = [b(Re, fe) for _ in range(self.Le)]
+        S.etmp = b(Re, d)
+        # encoder gradients (per layer, so the weight-gradient GEMMs can run after the sweep)
+        S.geh = [b(Re, d) for _ in range(self.Le + 1)]
+        S.gef2, S.gef1 = [b(Re, d) for _ in range(self.Le)], [b(Re, fe) for _ in range(self.Le)]
+        S.geh1, S.geo1 = [b(Re, d) for _ in range(self.Le)], [b(Re, d) for _ in range(self.Le)]
+        S.geatt, S.geqkv = [b(Re, d) for _ in range(self.Le)], [b(Re, 3 * d) for _ in range(self.Le)]
+        # decoder activations, step-major
+        L = self.Ld
+        S.pos = b(ph + 1, B, self.n_pos)
+        S.x = [b(ph, B, d) for _ in range(L + 1)]
+        S.qkv = [b(ph, B, 3 * d) for _ in range(L)]
+        S.p1 = [b(ph, B * H * ph) for _ in range(L)]
+        S.p2 = [b(ph, B * H * T) for _ in range(L)]
+        for n in ("a1", "x1", "cq", "a2", "x2", "xhat1", "xhat2", "xhat3"):
+            setattr(S, n, [b(ph, B, d) for _ in range(L)])
+        for n in ("rstd1", "rstd2", "rstd3"):
+            setattr(S, n, [b(ph, B) for _ in range(L)])
+        S.f1 = [b(ph, B, fd) for _ in range(L)]
+        S.mkv = [b(Re, 2 * d) for _ in range(L)]
+        S.tmp = b(B, d)
+        no, nh = self.n_out, len(self.head_hidden)
+        S.ho = b(ph, B, no)
+        S.hu = [b(ph, B, no) for _ in range(nh)]
+        S.hxhat = [b(ph, B, no) for _ in range(nh)]
+        S.hrstd = [b(ph, B) for _ in range(nh)]
+        S.htmp = b(B, no)
+        # decoder gradients, step-major (kept for the deferred weight-gradient GEMMs)
+        S.G = b(ph + 1, B, self.n_pos)
+        S.gx = [b(ph, B, d) for _ in range(L + 1)]
+        for n in ("gf2", "gx2", "go2", "ga2", "gcq", "gx1", "go1", "ga1"):
+            setattr(S, n, [b(ph, B, d) for _ in range(L)])
+        S.gf1 = [b(ph, B, fd) for _ in range(L)]
+        S.gqkv = [b(ph, B, 3 * d) for _ in range(L)]
+        S.gmkv = [b(Re, 2 * d) for _ in range(L)]
+        S.gho = b(ph, B, no)
+        S.ghu = [b(ph, B, no) for _ in range(nh)]       # grad wrt relu(LN(.)) output
+        S.ghum = [b(ph, B, no) for _ in range(nh)]      # the same, zeroed where relu was inactive
+        S.ghz = [b(ph, B, no) for _ in range(nh)]       # grad wrt the Linear output feeding the LayerNorm
+        self.s = S
+
+    # ------------------------------------------------------------------ forward
+    def set_batch(self, x_st, y_st):
+        if tuple(x_st.shape) != tuple(self.x_st.shape) or tuple(y_st.shape) != tuple(self.y_st.shape):
+            raise MmtError(f"batch shape {tuple(x_st.shape)} / {tuple(y_st.shape)} does not match the engine's "
+                           f"{tuple(self.x_st.shape)} / {tuple(self.y_st.shape)}")
+        self.x_st.copy_(x_st)
+        self.y_st.copy_(y_st)
+
+    def forward(self):
+        """Encoder -> memory K/V -> ph decoder steps with position feedback; everything the backward needs is kept."""
+        S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
+        enc, dec = self.enc, self.dec
+        K.history_prepare(self.x_st, S.x0, S.pad)
+        K.gemm(S.x0, _t(enc.input_fc.weight), S.eh[0], bias=enc.input_fc.bias, addend=S.pe_enc)
+        for l, lay in enumerate(enc.transformer_encoder.layers):
+            sa = lay.self_attn
+            K.gemm(S.eh[l], _t(sa.in_proj_weight), S.eqkv[l], bias=sa.in_proj_bias)
+            qkv = S.eqkv[l].view(B, T, 3 * d)
+            K.attention_fwd(qkv[:, :, 0:d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], S.eatt[l].view(B, T, d), S.eprobs[l],
+                            H, self.scale, pad=S.pad, causal=True)
+            K.gemm(S.eatt[l], _t(sa.out_proj.weight), S.etmp, bias=sa.out_proj.bias, addend=S.eh[l])
+            K.layernorm_fwd(S.etmp, None, lay.norm1.weight, lay.norm1.bias, S.eh1[l], S.exhat1[l], S.erstd1[l])
+            K.gemm(S.eh1[l], _t(lay.linear1.weight), S.ef1[l], bias=lay.linear1.bias, relu=True)
+            K.gemm(S.ef1[l], _t(lay.linear2.weight), S.etmp, bias=lay.linear2.bias, addend=S.eh1[l])
+            K.layernorm_fwd(S.etmp, None, lay.norm2.weight, lay.norm2.bias, S.eh[l + 1], S.exhat2[l], S.erstd2[l])
+        memory = S.eh[self.Le]
+        layers = dec.transformer_decoder.layers
+        for l, lay in enumerate(layers):
+            ca = lay.multihead_attn
+            K.gemm(memory, _t(ca.in_proj_weight[d:]), S.mkv[l], bias=ca.in_proj_bias[d:])
+        S.pos[0].copy_(self.x_st[:, -1, 0:self.n_pos])          # start token = standardised current position
+        for s in range(ph):
+            K.gemm(S.pos[s], _t(dec.input_fc.weight), S.x[0][s], bias=dec.input_fc.bias,
+                   addend=S.pe_dec[s:s + 1].expand(B, d))
+            for l, lay in enumerate(layers):
+                sa, ca = lay.self_attn, lay.multihead_attn
+                x = S.x[l][s]
+                K.gemm(x, _t(sa.in_proj_weight), S.qkv[l][s], bias=sa.in_proj_bias)
+                c = S.qkv[l]
+                K.attention_fwd(c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
+                                c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.a1[l][s:s + 1].permute(1, 0, 2),
+                                S.p1[l][s][:B * H * (s + 1)], H, self.scale)
+                K.gemm(S.a1[l][s], _t(sa.out_proj.weight), S.tmp, bias=sa.out_proj.bias, addend=x)
+                K.layernorm_fwd(S.tmp, None, lay.norm1.weight, lay.norm1.bias, S.x1[l][s], S.xhat1[l][s], S.rstd1[l][s])
+                K.gemm(S.x1[l][s], _t(ca.in_proj_weight[:d]), S.cq[l][s], bias=ca.in_proj_bias[:d])
+                mkv = S.mkv[l].view(B, T, 2 * d)
+                K.attention_fwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:],
+                                S.a2[l][s:s + 1].permute(1, 0, 2), S.p2[l][s], H, self.scale, pad=S.pad)
+                K.gemm(S.a2[l][s], _t(ca.out_proj.weight), S.tmp, bias=ca.out_proj.bias, addend=S.x1[l][s])
+                K.layernorm_fwd(S.tmp, None, lay.norm2.weight, lay.norm2.bias, S.x2[l][s], S.xhat2[l][s], S.rstd2[l][s])
+                K.gemm(S.x2[l][s], _t(lay.linear1.weight), S.f1[l][s], bias=lay.linear1.bias, relu=True)
+                K.gemm(S.f1[l][s], _t(lay.linear2.weight), S.tmp, bias=lay.linear2.bias, addend=S.x2[l][s])
+                K.layernorm_fwd(S.tmp, None, lay.norm3.weight, lay.norm3.bias, S.x[l + 1][s], S.xhat3[l][s],
+                                S.rstd3[l][s])
+            K.gemm(S.x[self.Ld][s], _t(dec.output_fc.weight), S.ho[s], bias=dec.output_fc.bias)
+            z = S.ho[s]
+            for i, (lin, ln) in enumerate(self.head_hidden):
+                K.gemm(z, _t(lin.weight), S.htmp, bias=lin.bias)
+                K.layernorm_fwd(S.htmp, None, ln.weight, ln.bias, S.hu[i][s], S.hxhat[i][s], S.hrstd[i][s], relu=True)
+                z = S.hu[i][s]
+            K.gemm(z, _t(self.head_out.weight), S.pos[s + 1], bias=self.head_out.bias, addend=S.pos[s])
+        # loss value and dL/dpos in one pass (mgcvae.py:614-620)
+        self.loss.zero_()
+        K.l2_loss_bwd(S.pos[1:], self.y_st, S.G[1:], self.loss)
+        return self.loss
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, dY, X, w, bias=None):
+        """gW = dY^T X over all rows, gb = column sums of dY."""
+        K.gemm(dY.t(), X, self.g(w))
+        if bias is not None:
+            K.colsum(dY, self.g(bias))
+
+    def _wgrad_rows(self, dY, X, gw, gb):
+        K.gemm(dY.t(), X, gw)
+        K.colsum(dY, gb)
+
+    def _ln_grad(self, dy, xhat, ln):
+        K.colsum(dy, self.g(ln.weight), b=xhat)
+        K.colsum(dy, self.g(ln.bias))
+
+    def backward(self):
+        """Reverse-time sweep.  ``forward`` must have run; ``S.G[1:]`` holds dL/dpos from the loss kernel."""
+        S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
+        enc, dec = self.enc, self.dec
+        layers = dec.transformer_decoder.layers
+        L, nh = self.Ld, len(self.head_hidden)
+        for l in range(L):
+            S.gqkv[l].zero_()
+            S.gmkv[l].zero_()
+        for s in range(ph - 1, -1, -1):
+            # head: pos[s+1] = pos[s] + out(relu(LN(lin(.)))...)   (MLP.py:12-24, mgcvae.py:445)
+            gin = S.G[s + 1]
+            w = self.head_out.weight
+            for i in range(nh - 1, -1, -1):
+                lin, ln = self.head_hidden[i]
+                K.gemm(gin, w, S.ghu[i][s])
+                K.layernorm_bwd(S.ghu[i][s], S.hxhat[i][s], S.hrstd[i][s], ln.weight, S.ghz[i][s], y_relu=S.hu[i][s],
+                                dy_masked=S.ghum[i][s])
+                gin, w = S.ghz[i][s], lin.weight
+            K.gemm(gin, w, S.gho[s])
+            K.gemm(S.gho[s], dec.output_fc.weight, S.gx[L][s])
+            for l in range(L - 1, -1, -1):
+                lay = layers[l]
+                sa, ca = lay.self_attn, lay.multihead_attn
+                K.layernorm_bwd(S.gx[l + 1][s], S.xhat3[l][s], S.rstd3[l][s], lay.norm3.weight, S.gf2[l][s])
+                K.gemm(S.gf2[l][s], lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s])
+                K.gemm(S.gf1[l][s], lay.linear1.weight, S.gx2[l][s], addend=S.gf2[l][s])
+                K.layernorm_bwd(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s])
+                K.gemm(S.go2[l][s], ca.out_proj.weight, S.ga2[l][s])
+                mkv, gmkv = S.mkv[l].view(B, T, 2 * d), S.gmkv[l].view(B, T, 2 * d)
+                K.attention_bwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s],
+                                S.ga2[l][s:s + 1].permute(1, 0, 2), S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d],
+                                gmkv[:, :, d:], H, self.scale)
+                K.gemm(S.gcq[l][s], ca.in_proj_weight[:d], S.gx1[l][s], addend=S.go2[l][s])
+                K.layernorm_bwd(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s])
+                K.gemm(S.go1[l][s], sa.out_proj.weight, S.ga1[l][s])
+                c, gc = S.qkv[l], S.gqkv[l]
+                K.attention_bwd(c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
+                                c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s][:B * H * (s + 1)],
+                                S.ga1[l][s:s + 1].permute(1, 0, 2), gc[s:s + 1, :, 0:d].permute(1, 0, 2),
+                                gc[0:s + 1, :, d:2 * d].permute(1, 0, 2), gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), H,
+                                self.scale)
+                K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s])
+            if s > 0:      # G[s] = dL/dpos[s] (already there) + residual path + embedding path
+                K.gemm(S.gx[0][s], dec.input_fc.weight, S.G[s], addend=S.G[s + 1], accumulate=True)
+        # ---- deferred decoder weight gradients: one GEMM per Linear over all ph*B rows
+        R = ph * B
+        f2 = lambda t: t.view(R, t.shape[-1])
+        self._wgrad(f2(S.gx[0]), f2(S.pos[:ph]), dec.input_fc.weight, dec.input_fc.bias)
+        memory = S.eh[self.Le]
+        for l, lay in enumerate(layers):
+            sa, ca = lay.self_attn, lay.multihead_attn
+            self._wgrad(f2(S.gqkv[l]), f2(S.x[l]), sa.in_proj_weight, sa.in_proj_bias)
+            self._wgrad(f2(S.go1[l]), f2(S.a1[l]), sa.out_proj.weight, sa.out_proj.bias)
+            self._ln_grad(f2(S.gx1[l]), f2(S.xhat1[l]), lay.norm1)
+            gw, gb = self.g(ca.in_proj_weight), self.g(ca.in_proj_bias)
+            self._wgrad_rows(f2(S.gcq[l]), f2(S.x1[l]), gw[:d], gb[:d])
+            self._wgrad_rows(S.gmkv[l], memory, gw[d:], gb[d:])
+            self._wgrad(f2(S.go2[l]), f2(S.a2[l]), ca.out_proj.weight, ca.out_proj.bias)
+            self._ln_grad(f2(S.gx2[l]), f2(S.xhat2[l]), lay.norm2)
+            self._wgrad(f2(S.gf1[l]), f2(S.x2[l]), lay.linear1.weight, lay.linear1.bias)
+            self._wgrad(f2(S.gf2[l]), f2(S.f1[l]), lay.linear2.weight, lay.linear2.bias)
+            self._ln_grad(f2(S.gx[l + 1]), f2(S.xhat3[l]), lay.norm3)
+        self._wgrad(f2(S.gho), f2(S.x[L]), dec.output_fc.weight, dec.output_fc.bias)
+        z = S.ho
+        for i, (lin, ln) in enumerate(self.head_hidden):
+            self._wgrad(f2(S.ghz[i]), f2(z), lin.weight, lin.bias)
+            self._ln_grad(f2(S.ghum[i]), f2(S.hxhat[i]), ln)
+            z = S.hu[i]
+        self._wgrad(f2(S.G[1:]), f2(z), self.head_out.weight, self.head_out.bias)
+        # ---- encoder: d memory = sum over decoder layers of d(memory K/V) W_kv
+        gmem = S.geh[self.Le]
+        for l, lay in enumerate(layers):
+            K.gemm(S.gmkv[l], lay.multihead_attn.in_proj_weight[d:], gmem, accumulate=(l > 0))
+        for l in range(self.Le - 1, -1, -1):
+            lay = enc.transformer_encoder.layers[l]
+            sa = lay.self_attn
+            K.layernorm_bwd(S.geh[l + 1], S.exhat2[l], S.erstd2[l], lay.norm2.weight, S.gef2[l])
+            K.gemm(S.gef2[l], lay.linear2.weight, S.gef1[l], mask=S.ef1[l])
+            K.gemm(S.gef1[l], lay.linear1.weight, S.geh1[l], addend=S.gef2[l])
+            K.layernorm_bwd(S.geh1[l], S.exhat1[l], S.erstd1[l], lay.norm1.weight, S.geo1[l])
+            K.gemm(S.geo1[l], sa.out_proj.weight, S.geatt[l])
+            S.geqkv[l].zero_()
+            qkv, gq = S.eqkv[l].view(B, T, 3 * d), S.geqkv[l].view(B, T, 3 * d)
+            K.attention_bwd(qkv[:, :, 0:d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], S.eprobs[l], S.geatt[l].view(B, T, d),
+                            gq[:, :, 0:d], gq[:, :, d:2 * d], gq[:, :, 2 * d:], H, self.scale)
+            K.gemm(S.geqkv[l], sa.in_proj_weight, S.geh[l], addend=S.geo1[l])
+            self._wgrad(S.gef2[l], S.ef1[l], lay.linear2.weight, lay.linear2.bias)
+            self._ln_grad(S.geh[l + 1], S.exhat2[l], lay.norm2)
+            self._wgrad(S.gef1[l], S.eh1[l], lay.linear1.weight, lay.linear1.bias)
+            self._ln_grad(S.geh1[l], S.exhat1[l], lay.norm1)
+            self._wgrad(S.geo1[l], S.eatt[l], sa.out_proj.weight, sa.out_proj.bias)
+            self._wgrad(S.geqkv[l], S.eh[l], sa.in_proj_weight, sa.in_proj_bias)
+        self._wgrad(S.geh[0], S.x0, enc.input_fc.weight, enc.input_fc.bias)
+
+    # ------------------------------------------------------------------ convenience
+    def predictions(self):
+        """Standardised positions (B, ph, 2) of the last forward."""
+        return self.s.pos[1:].permute(1, 0, 2).contiguous()
+
+
+class _TrainLossFn(torch.autograd.Function):
+    """Lets the reference's loop (``loss.backward(); clip; optimizer.step()``, train.py:244-253) drive the HIP
+    backward: the parameters are the function's inputs, their gradients are slices of the engine's flat buffer."""
+
+    @staticmethod
+    def forward(ctx, engine, *params):
+        ctx.engine = engine
+        engine.forward()
+        return engine.loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.engine
+        eng.backward()
+        eng.flat_grad.mul_(gout)
+        return (None,) + tuple(eng.g(p) for _, p in eng.named_params)
+
+
+def train_loss_with_graph(model, x_st, y_st, ph):
+    """``MultimodalGenerativeCVAE.train_loss`` body for the Basic configuration: a scalar that carries autograd."""
+    B, T, _ = x_st.shape
+    key = (B, T, ph)
+    cache = model.__dict__.setdefault("_train_engines", {})
+    eng = cache.get(key)
+    if eng is None:
+        eng = cache[key] = TrainEngine(model, B, T, ph)
+    eng.set_batch(x_st, y_st)
+    return _TrainLossFn.apply(eng, *[p for _, p in eng.named_params])
+
+
+class Trainer:
+    """Fused training step: forward + backward (one HIP graph), gradient all-reduce over RCCL when
+    ``torch.distributed`` is initialised, clip-by-value + AdamW + ExponentialLR (second graph).
+
+    Optimizer semantics are train.py:218-256: AdamW(lr=hp.learning_rate, betas .9/.999, eps 1e-8, weight decay
+    0.01), second parameter group 'map_encoder' at lr 8e-4, ``clip_grad_value_(hp.grad_clip)`` on the averaged
+    gradient, ExponentialLR(hp.learning_decay_rate) stepped once per batch."""
+
+    def __init__(self, model, B, T, ph, use_graph=True, process_group=None, distributed=True):
+        import torch.distributed as dist
+        hp = model.hyperparams
+        self.engine = TrainEngine(model, B, T, ph)
+        self.hp = hp
+        self.world = 1
+        if distributed and dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size(process_group)
+        self.pg = process_group
+        self.lr0 = float(hp["learning_rate"])
+        self.gamma = float(hp["learning_decay_rate"]) if hp.get("learning_rate_style", "exp") == "exp" else 1.0
+        self.clip = float(hp["grad_clip"]) if hp.get("grad_clip") is not None else 0.0
+        self.betas, self.eps, self.wd = (0.9, 0.999), 1e-8, 0.01
+        dev = self.engine.device
+        self.state = torch.tensor([1.0, self.lr0], dtype=torch.float32).to(dev)
+        entries, self.moments = [], []
+        for name, p in self.engine.named_params:
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            self.moments.append((m, v))
+            scale = (0.0008 / self.lr0) if "map_encoder" in name else 1.0
+            entries.append((p.data, self.engine.g(p), m, v, scale))
+        self.table, self.ntensors = K.adamw_table(entries, dev)
+        self.use_graph = use_graph
+        self._g_fb = self._g_opt = None
+        self.steps_done = 0
+
+    def _fwd_bwd(self):
+        self.engine.forward()
+        self.engine.backward()
+
+    def _opt(self):
+        K.adamw_step(self.table, self.ntensors, self.state, self.betas[0], self.betas[1], self.eps, self.wd, self.clip,
+                     1.0 / self.world)
+        K.lr_step(self.state, self.gamma)
+
+    def _capture(self):
+        # warm-up on a side stream (allocations, library loading), then capture both halves
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self._fwd_bwd()
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt):
+            self._opt()
+
+    def step(self, x_st, y_st):
+        """One optimisation step on this rank's shard; returns the local loss as a 1-element device tensor."""
+        self.engine.set_batch(x_st, y_st)
+        if self.use_graph:
+            if self._g_fb is None:
+                self._capture()
+            self._g_fb.replay()
+        else:
+            self._fwd_bwd()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.engine.flat_grad, group=self.pg)      # one flat fp32 bucket
+        if self.use_graph:
+            self._g_opt.replay()
+        else:
+            self._opt()
+        self.steps_done += 1
+        # the kernels wrote the parameters through raw pointers (no torch version bump): drop the packed
+        # inference copies so that the next predict() re-packs the updated weights
+        for mod in (self.engine.enc, self.engine.dec, self.engine.head):
+            mod.__dict__.pop("_pack_cache", None)
+            mod.__dict__.pop("_pack_cache_dec", None)
+        return self.engine.loss

@@ -1,0 +1,158 @@
+"""TEST INFRASTRUCTURE ONLY: torch/CPU stand-ins for the eight training kernels of
+``multimodal_transformer_amd/_train_kernels.py``, with the same argument conventions.
+
+They exist so that the *host orchestration* in ``training.py`` (which buffer feeds which kernel, the reverse-time
+order, the deferred weight-gradient GEMMs) can be checked against the reference's autograd goldens in the CPU
+test tier.  The product never imports this file; on a GPU box the real HIP kernels are what run
+(tests/test_gpu_training.py checks those against the same goldens).
+"""
+import torch
+
+
+def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False):
+    v = A.double() @ B.double()
+    if bias is not None:
+        v = v + bias.double()
+    if addend is not None:
+        v = v + addend.double()
+    if relu:
+        v = torch.relu(v)
+    if mask is not None:
+        v = torch.where(mask > 0, v, torch.zeros_like(v))
+    v = v.to(Cm.dtype)
+    if accumulate:
+        Cm.add_(v)
+    else:
+        Cm.copy_(v)
+
+
+def colsum(a, out, b=None, mask=None, accumulate=False):
+    v = a.double()
+    if b is not None:
+        v = v * b.double()
+    if mask is not None:
+        v = torch.where(mask > 0, v, torch.zeros_like(v))
+    v = v.sum(0).to(out.dtype)
+    if accumulate:
+        out.add_(v)
+    else:
+        out.copy_(v)
+
+
+def layernorm_fwd(x, res, g, b, y, xhat, rstd, relu=False):
+    v = x.double() + (res.double() if res is not None else 0.0)
+    mu = v.mean(-1, keepdim=True)
+    var = ((v - mu) ** 2).mean(-1, keepdim=True)
+    r = 1.0 / torch.sqrt(var + 1e-5)
+    h = (v - mu) * r
+    o = h * g.double() + b.double()
+    if relu:
+        o = torch.relu(o)
+    y.copy_(o.to(y.dtype))
+    xhat.copy_(h.to(xhat.dtype))
+    rstd.copy_(r[:, 0].to(rstd.dtype))
+
+
+def layernorm_bwd(dy, xhat, rstd, g, dx, y_relu=None, dy_masked=None, accumulate=False):
+    d = dy.double()
+    if y_relu is not None:
+        d = torch.where(y_relu > 0, d, torch.zeros_like(d))
+    if dy_masked is not None:
+        dy_masked.copy_(d.to(dy_masked.dtype))
+    dg = d * g.double()
+    xh = xhat.double()
+    m1 = dg.mean(-1, keepdim=True)
+    m2 = (dg * xh).mean(-1, keepdim=True)
+    v = (rstd.double()[:, None] * (dg - m1 - xh * m2)).to(dx.dtype)
+    if accumulate:
+        dx.add_(v)
+    else:
+        dx.copy_(v)
+
+
+def _heads(t, H):
+    B, L, d = t.shape
+    return t.double().reshape(B, L, H, d // H).permute(0, 2, 1, 3)          # (B,H,L,dh)
+
+
+def attention_fwd(q, k, v, o, probs, nhead, scale, pad=None, causal=False, causal_offset=0):
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    s = _heads(q, nhead) @ _heads(k, nhead).transpose(-1, -2) * scale       # (B,H,Lq,Lk)
+    keep = torch.ones(B, 1, Lq, Lk, dtype=torch.bool)
+    if causal:
+        i = torch.arange(Lq)[:, None]
+        j = torch.arange(Lk)[None, :]
+        keep = keep & (j < i + 1 + causal_offset)[None, None]
+    if pad is not None:
+        keep = keep & ~(pad.bool()[:, None, None, :])
+    s = s.masked_fill(~keep, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)                                       # fully masked row -> zeros (kernel convention)
+    probs.copy_(p.reshape(-1).to(probs.dtype))
+    out = (p @ _heads(v, nhead)).permute(0, 2, 1, 3).reshape(B, Lq, d)
+    o.copy_(out.to(o.dtype))
+
+
+def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale):
+    B, Lq, d = q.shape
+    Lk = k.shape[1]
+    p = probs.double().view(B, nhead, Lq, Lk)
+    g = _heads(d_o, nhead)
+    dp = g @ _heads(v, nhead).transpose(-1, -2)
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True)) * scale
+    merge = lambda t, L: t.permute(0, 2, 1, 3).reshape(B, L, d)
+    dq.copy_(merge(ds @ _heads(k, nhead), Lq).to(dq.dtype))
+    dk.add_(merge(ds.transpose(-1, -2) @ _heads(q, nhead), Lk).to(dk.dtype))
+    dv.add_(merge(p.transpose(-1, -2) @ g, Lk).to(dv.dtype))
+
+
+def l2_loss_bwd(pos, y, dpos, loss_sum=None):
+    ph, B, _ = pos.shape
+    diff = pos.double() - y.double().permute(1, 0, 2)
+    n = diff.norm(dim=-1, keepdim=True)
+    w = torch.where(n > 0, 1.0 / (n * B * ph), torch.zeros_like(n))
+    dpos.copy_((diff * w).to(dpos.dtype))
+    if loss_sum is not None:
+        loss_sum.add_((n.sum() / (B * ph)).to(loss_sum.dtype))
+
+
+def history_prepare(x_st, x0, pad):
+    B, T, n = x_st.shape
+    x0.copy_(torch.nan_to_num(x_st, nan=0.0).reshape(B * T, n))
+    pad.copy_(torch.isnan(x_st)[:, :, 1].to(torch.uint8))
+
+
+def adamw_table(entries, device):
+    return list(entries), len(entries)
+
+
+def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, grad_scale):
+    step, lr0 = float(state[0]), float(state[1])
+    for p, g, m, v, s in table:
+        lr = lr0 * s
+        gg = g * grad_scale
+        if clip > 0:
+            gg = gg.clamp(-clip, clip)
+        p.mul_(1.0 - lr * weight_decay)
+        m.mul_(beta1).add_(gg, alpha=1.0 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1.0 - beta2)
+        denom = v.sqrt() / (1.0 - beta2 ** step) ** 0.5 + eps
+        p.addcdiv_(m, denom, value=-lr / (1.0 - beta1 ** step))
+
+
+def lr_step(state, gamma):
+    state[0] += 1.0
+    state[1] *= gamma
+
+
+ALL = ("gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
+       "history_prepare", "adamw_table", "adamw_step", "lr_step")
+
+
+def install(monkeypatch):
+    import sys
+    from multimodal_transformer_amd import _train_kernels as K
+    me = sys.modules[__name__]
+    for n in ALL:
+        monkeypatch.setattr(K, n, torch.no_grad()(getattr(me, n)))   # the real kernels never build autograd graphs

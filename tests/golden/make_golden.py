@@ -172,6 +172,8 @@ def run_mode(mode, tiny):
             grad_norms[key] = None if p.grad is None else float(p.grad.double().norm())
             if tiny and p.grad is not None:
                 out["grad::" + key] = p.grad.numpy().copy()
+            elif p.grad is not None:     # full size: the first 256 elements of every gradient, element-wise pin
+                out["gradhead::" + key] = p.grad.reshape(-1)[:256].numpy().copy()
     meta["grad_norms"] = grad_norms
     nn.utils.clip_grad_value_(reg.parameters(), hp["grad_clip"])
     opt.step()
@@ -181,6 +183,9 @@ def run_mode(mode, tiny):
                 out["post::" + f"{name}.{pn_}"] = p.detach().numpy().copy()
     else:
         meta["post_step_checksum"] = checksum(reg.model_dict)
+        for name, mod in reg.model_dict.items():
+            for pn_, p in mod.named_parameters():
+                out["posthead::" + f"{name}.{pn_}"] = p.detach().reshape(-1)[:256].numpy().copy()
 
     if tiny:
         # weights BEFORE the step and inputs (regenerable, but committed so the tiny set is self-contained)

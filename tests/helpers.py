@@ -58,3 +58,19 @@ def rel_err(a, b, floor=None):
     if floor is None:
         floor = float(np.sqrt(np.mean(b * b))) + 1e-30
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def check_post_step(p_new, post_ref, grad_ref, lr, tol=1e-4):
+    """Post-AdamW parameters against the reference's.  The first AdamW step moves every element by
+    lr * g / (|g| + 1e-8): where the reference gradient is numerically zero (|g| < 1e-7, e.g. the key bias of an
+    attention layer, whose true gradient is 0 by softmax shift invariance) the update is the sign of rounding
+    noise and may legitimately differ by up to 2*lr; everywhere else the parameters must agree to ``tol``."""
+    p_new, post_ref = np.asarray(p_new, np.float64), np.asarray(post_ref, np.float64)
+    if grad_ref is None:
+        return float(np.max(np.abs(p_new - post_ref))) == 0.0, 0.0
+    solid = np.abs(np.asarray(grad_ref)) >= 1e-7
+    floor = float(np.sqrt(np.mean(post_ref * post_ref))) + 1e-30
+    err = np.abs(p_new - post_ref)
+    ok_solid = (not solid.any()) or float(np.max(err[solid] / np.maximum(np.abs(post_ref[solid]), floor))) <= tol
+    ok_noise = solid.all() or float(np.max(err[~solid])) <= 2.1 * lr
+    return ok_solid and ok_noise, float(err.max())

@@ -1,0 +1,135 @@
+"""CPU tier: the host orchestration of the training step (multimodal_transformer_amd/training.py) against the
+reference's autograd goldens.  The HIP kernels are replaced by tests/fake_kernels.py (torch stand-ins with the
+same argument conventions), so what is pinned here is the *graph*: forward-with-stash, the reverse-time sweep
+through the KV-cached decoder, the deferred weight-gradient GEMMs, clip + AdamW + LR schedule.
+The kernels themselves are pinned on the GPU by tests/test_gpu_training.py."""
+import numpy as np
+import pytest
+import torch
+
+import fake_kernels
+from helpers import batch_for, check_post_step, hp_for, load_golden, rel_err, set_weights
+
+GRAD_TOL = 1e-4
+
+
+class _Env:
+    robot_type = None
+
+
+def _model(hp):
+    from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+    reg = ModelRegistrar("/tmp", "cpu")
+    return MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, "cpu", []), reg
+
+
+def _tiny_engine(monkeypatch):
+    from multimodal_transformer_amd import training
+    fake_kernels.install(monkeypatch)
+    z, meta = load_golden("tiny_basic")
+    hp, B, ph = hp_for("basic", True)
+    hp["autoregressive"] = True
+    model, reg = _model(hp)
+    set_weights(reg.model_dict, True, z)
+    batch = batch_for("basic", True)
+    x_st, y_st = torch.from_numpy(batch["x_st"]), torch.from_numpy(batch["y_st"])
+    return training, model, reg, z, meta, hp, x_st, y_st, ph
+
+
+def test_forward_backward_match_reference_autograd(monkeypatch):
+    training, model, reg, z, meta, hp, x_st, y_st, ph = _tiny_engine(monkeypatch)
+    eng = training.TrainEngine(model, x_st.shape[0], x_st.shape[1], ph)
+    eng.set_batch(x_st, y_st)
+    loss = eng.forward()
+    assert abs(float(loss) - float(z["train_loss"])) <= 1e-5 * abs(float(z["train_loss"]))
+    eng.backward()
+    # exactly the parameters the reference gives a gradient to
+    want = {k for k, v in meta["grad_norms"].items() if v is not None}
+    assert set(eng.grad_by_name) == want
+    worst = 0.0
+    for name, g in eng.grad_by_name.items():
+        e = rel_err(g.numpy(), z["grad::" + name])
+        worst = max(worst, e)
+        assert e <= GRAD_TOL, (name, e)
+    print("worst gradient rel err", worst)
+
+
+def test_fused_step_matches_reference_adamw(monkeypatch):
+    training, model, reg, z, meta, hp, x_st, y_st, ph = _tiny_engine(monkeypatch)
+    tr = training.Trainer(model, x_st.shape[0], x_st.shape[1], ph, use_graph=False)
+    loss = tr.step(x_st, y_st)
+    assert abs(float(loss) - float(z["train_loss"])) <= 1e-5 * abs(float(z["train_loss"]))
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            ok, e = check_post_step(p.detach().numpy(), z["post::" + key], z["grad::" + key] if "grad::" + key in z.files
+                                    else None, hp["learning_rate"])
+            assert ok, (key, e)
+    assert float(tr.state[0]) == 2.0
+    assert abs(float(tr.state[1]) - hp["learning_rate"] * hp["learning_decay_rate"]) < 1e-10
+
+
+def test_autograd_entry_point_drives_reference_style_loop(monkeypatch):
+    """loss.backward(); clip_grad_value_; torch AdamW.step() -- the reference's own loop (train.py:244-253)."""
+    training, model, reg, z, meta, hp, x_st, y_st, ph = _tiny_engine(monkeypatch)
+    opt = torch.optim.AdamW(
+        [{"params": reg.get_all_but_name_match("map_encoder").parameters()},
+         {"params": reg.get_name_match("map_encoder").parameters(), "lr": 0.0008}], lr=hp["learning_rate"])
+    opt.zero_grad()
+    batch = batch_for("basic", True)
+    x, y = torch.from_numpy(batch["x"]), torch.from_numpy(batch["y"])
+    loss, reg_loss = model.train_loss(x, x_st, None, None, None, y, y_st, None, ph)
+    assert loss.requires_grad
+    loss.backward()
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            if meta["grad_norms"][key] is None:
+                assert p.grad is None, key
+            else:
+                assert rel_err(p.grad.numpy(), z["grad::" + key]) <= GRAD_TOL, key
+    torch.nn.utils.clip_grad_value_(reg.parameters(), hp["grad_clip"])
+    opt.step()
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            ok, e = check_post_step(p.detach().numpy(), z["post::" + key], z["grad::" + key] if "grad::" + key in z.files
+                                    else None, hp["learning_rate"])
+            assert ok, (key, e)
+
+
+def test_ragged_shape_gradients_match_torch_autograd_of_the_oracle(monkeypatch):
+    """Shapes the goldens do not cover (B=3, T=7, ph=5): the engine's gradients against torch autograd run on the
+    explicit-arithmetic fp64 oracle."""
+    from oracle import restatement as rs
+    from multimodal_transformer_amd import training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    from helpers import TINY_TR
+    fake_kernels.install(monkeypatch)
+    hp = make_hyperparams("basic", history=6, horizon=5, transformer=TINY_TR)
+    hp["autoregressive"] = True
+    model, reg = _model(hp)
+    apply_recipe(reg.model_dict, seed=7)
+    batch = make_batch(3, 6, 5, seed=4)
+    x_st, y_st = torch.from_numpy(batch["x_st"]), torch.from_numpy(batch["y_st"])
+    eng = training.TrainEngine(model, 3, 7, 5)
+    eng.set_batch(x_st, y_st)
+    loss = eng.forward()
+    eng.backward()
+    w = rs.flatten_modules(reg.model_dict)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items() if v.is_floating_point() and not k.endswith(".pe")}
+    w2 = dict(w)
+    w2.update(leaves)
+    memory, pad = rs.encoder_forward(w2, x_st.double(), hp["transformer"]["nhead"])
+    pos, _ = rs.decoder_ar(w2, memory, pad, x_st[:, -1, 0:2].double(), hp["transformer"]["nhead"], 5)
+    ref = (pos - y_st.double()).norm(dim=-1).mean(-1).mean()
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    alias = {"VEHICLE/node_history_encoder": "enc", "VEHICLE/decoder/transformer_decoder": "dec",
+             "VEHICLE/decoder/MLP": "head"}
+    for name, g in eng.grad_by_name.items():
+        key, pn = name.rsplit("/", 1)[0] + "/" + name.rsplit("/", 1)[1].split(".", 1)[0], name.rsplit("/", 1)[1].split(".", 1)[1]
+        want = leaves[f"{alias[key]}.{pn}"].grad
+        assert rel_err(g.numpy(), want.numpy()) <= GRAD_TOL, name
