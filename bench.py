@@ -112,6 +112,79 @@ def cpu_baseline(mode, hp, batch, ph, max_seconds=25.0):
                       f"eval mode, no_grad, anomaly detection off; os.cpu_count()={os.cpu_count()}"}
 
 
+def cpu_train_baseline(hp, batch, ph, max_seconds=25.0):
+    """Reference-form training step (stock torch.nn modules, autograd, clip, torch AdamW; dropout 0, anomaly
+    detection off) on the host cores: 1 warm-up + up to 3 timed steps (bounded)."""
+    from oracle import reference_form as rf          # baseline only
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    ref = rf.ReferenceFormModel(hp)
+    apply_recipe(ref.m, seed=0)
+    ref.m.train()
+    for m in ref.m.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    c = {k: torch.from_numpy(v) for k, v in batch.items()}
+    opt = torch.optim.AdamW(ref.m.parameters(), lr=hp["learning_rate"])
+    times = []
+    t_begin = time.perf_counter()
+    for i in range(4):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = ref.train_loss(c["x"], c["x_st"], c["y"], c["y_st"], c.get("lanes"), c.get("map"), ph)
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(ref.m.parameters(), hp["grad_clip"])
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i >= 1:
+            times.append(dt)
+        if time.perf_counter() - t_begin > max_seconds and times:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} timed fwd+bwd+clip+AdamW steps at B={c['x'].shape[0]} after 1 warm-up, median; "
+                      "oracle/reference_form.py, dropout 0, anomaly detection off"}
+
+
+def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, dist):
+    """BASELINE config 2: Basic transformer training step (fwd + bwd + clip + AdamW), data-parallel with one flat
+    RCCL gradient all-reduce per step, 128 agents per GPU (global batch 128 * world)."""
+    from multimodal_transformer_amd.training import Trainer
+    hp["autoregressive"] = True
+    batches = [make_batch(B, history, ph, seed=100 + 10 * rank + i) for i in range(4)]
+    dev_batches = [(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev)) for b in batches]
+    tr = Trainer(model, B, history + 1, ph, use_graph=True)
+    for i in range(warmup):
+        tr.step(*dev_batches[i % 4])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = tr.step(*dev_batches[i % 4])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(loss).all()
+    n_par = sum(p.numel() for _, p in tr.engine.named_params)
+    return {"metric": "train steps/sec (fwd+bwd+clip+AdamW)", "value": steps / elapsed, "unit": "steps/s",
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "per_gpu_batch": B,
+            "global_batch": B * world, "agents_per_s": B * world * steps / elapsed,
+            "parallelism": f"dp{world}, one flat fp32 all-reduce of {n_par} gradients per step (RCCL)" if world > 1
+            else "single GPU", "dropout": 0.0, "last_loss": float(loss),
+            "algorithmic_tflops": 3 * (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * world * steps / elapsed / 1e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +196,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also time larger per-GPU batches (extra keys)")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (extra key 'train')")
+    ap.add_argument("--train-steps", type=int, default=30)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +246,14 @@ def main():
     res = out[1] if args.mode == "lane_cnn" else out[0]
     assert torch.isfinite(res).all()
 
+    train = None
+    if args.mode == "basic" and not args.no_train:       # every rank takes part (all-reduce inside)
+        try:
+            train = bench_train(model, hp, dev, B, args.history, ph, rank, world, args.train_steps,
+                                max(3, min(args.warmup, 5)), dist if distributed else None)
+        except Exception as e:       # the headline metric must survive a failure of the extra leg
+            train = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
@@ -212,8 +295,11 @@ def main():
                                   "mfma_frac": (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * bb / dt / 1e12
                                   / PEAK_F32_MFMA_TFLOPS}
             line["batch_sweep"] = sweep
+        line["train"] = train
         if not args.no_cpu_baseline and not distributed:
             line["cpu_baseline"] = cpu_baseline(args.mode, hp, batch, ph)
+            if train is not None and "error" not in train:
+                train["cpu_baseline"] = cpu_train_baseline(hp, batch, ph)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
