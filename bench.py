@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also time larger per-GPU batches (extra keys)")
+    ap.add_argument("--decoder", default="auto", choices=["auto", "persistent", "cluster"],
+                    help="kernel family behind mmt_decoder_forward (include/mmt_amd.h)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (extra key 'train')")
     ap.add_argument("--train-steps", type=int, default=30)
     args = ap.parse_args()
@@ -214,6 +216,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    from multimodal_transformer_amd import ops
+    ops.decoder_select(args.decoder)
     B, ph = args.batch, args.horizon
     hp, model, reg = build_model(args.mode, dev, args.history, ph)
     # every rank gets its own shard of the global synthetic batch (seeded by rank): no collective on the data path

@@ -185,6 +185,15 @@ int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, int B, int T,
  *      (Trajectory_Decoder.forward, Transformer_model.py:168-199; h_out is then the result).
  * workspace: mmt_decoder_workspace_floats(...) floats. */
 size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph);
+/* Two implementations sit behind mmt_decoder_forward (tuning knob, no counterpart in the reference):
+ *   PERSISTENT: one launch, every workgroup owns <= 16 agents and streams all decoder weights each step;
+ *   CLUSTER   : 3 short launches per layer per step, 16 agents x nhead workgroups share one sub-layer
+ *               (weights split by head / FFN slice, partial sums reduced at the kernel boundary).
+ * AUTO (default) picks CLUSTER whenever the geometry allows it (d <= 256, head dim 16/32, d_ff/nhead <= 64). */
+#define MMT_DECODER_AUTO 0
+#define MMT_DECODER_PERSISTENT 1
+#define MMT_DECODER_CLUSTER 2
+int mmt_decoder_select(int impl);
 int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
                         const float *start_pos, const float *map_feat, int map_dim,
                         const float *mem_feat, int mem_feat_dim, const float *tgt, int B, int T, int ph,

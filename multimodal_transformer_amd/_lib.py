@@ -12,6 +12,7 @@ import os
 MMT_MAX_LAYERS = 8
 MMT_MAX_MLP_HIDDEN = 3
 MMT_MAX_CONV = 4
+MMT_DECODER_AUTO, MMT_DECODER_PERSISTENT, MMT_DECODER_CLUSTER = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMT_AMD_LIB", os.path.join(_HERE, "libmmt_amd.so"))   # override: diagnostic builds only
@@ -103,6 +104,7 @@ SIGNATURES = {
     "mmt_pack_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_encoder_forward": (C.c_int, [C.POINTER(Encoder), fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_decoder_workspace_floats": (C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
+    "mmt_decoder_select": (C.c_int, [C.c_int]),
     "mmt_decoder_forward": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
                                       C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
     "mmt_cnn_workspace_floats": (C.c_size_t, [C.POINTER(Cnn), C.c_int]),

@@ -1,0 +1,873 @@
+// Cluster decoder for gfx950 (MI355X): the KV-cached autoregressive decode (mgcvae.py:375-449,
+// Transformer_model.py:62-109,155-199, MLP.py:6-30) as a chain of short, wide kernels.
+//
+// Why: one new token per agent per step leaves only B rows of work per sub-layer.  The persistent kernel
+// (transformer.hip) gives every workgroup the whole weight stream (18.9 MB per step through one CU, which
+// takes in ~50 GB/s); here RC <= 16 agents form a "cluster" whose sub-layer is split Megatron-style over
+// H workgroups:
+//   phase A (self attention)  : workgroup h computes q_h,k_h,v_h, appends to the KV cache, attends, and
+//                               multiplies by the K-slice h of the out-projection     -> partial [RC][d]
+//   phase B (cross attention) : workgroup h: q_h, attention on the precomputed memory K/V, K-slice of out-proj
+//   phase C (feed forward)    : workgroup g: d_ff/H hidden columns (ReLU), K-slice of linear2
+// Every phase starts by summing the previous phase's H partials (+ bias + residual) and applying the
+// LayerNorm, redundantly in each workgroup of the cluster (fixed order: bit-reproducible and independent
+// of the batch size and of RC).  A kernel boundary is the all-reduce: 3 launches per layer per step, no
+// in-kernel spinning.  Everything a workgroup needs from memory (its weight slice <= 128 KB, biases, the
+// partials, its heads' K/V cache rows) is requested at kernel entry in one burst; K/V rows are read as
+// whole 128-byte lines and staged in LDS.
+// The head (output_fc, optional map fusion, decoder MLP, position feedback) and the embedding of the next
+// token ride at the front of the next step's first phase A.
+#include "mmt_device.cuh"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
+
+#ifdef MMT_PROFILE
+// diagnostic build: wall-clock (100 MHz) stamps per launch / workgroup / stage, read by tools/cluster_profile.py
+#define CLP_LAUNCHES 256
+#define CLP_WGS 64
+__device__ unsigned long long g_clprof[CLP_LAUNCHES][CLP_WGS][8];
+#define CSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < CLP_WGS && a.prof_idx < CLP_LAUNCHES) g_clprof[a.prof_idx][blockIdx.x][k] = wall_clock64(); } while (0)
+extern "C" int mmt_debug_read_clprof(unsigned long long *host, size_t n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clprof), sizeof(unsigned long long) * n);
+}
+#else
+#define CSTAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int CNT = 512;          // threads per workgroup
+constexpr int CNW = 8;            // waves per workgroup
+constexpr int KS_SMAX = 6;        // most 16-column slabs a K-split linear produces (3*DH/16 at DH = 32)
+constexpr int LDO = 72;           // row stride of the small LDS tiles (<= 64 columns + 8)
+constexpr int LDTOK = 24;
+constexpr int CHAIN_MAX = 4;
+constexpr int KMAX = 16;          // most keys an attention sees (history / horizon <= 16; else: persistent kernel)
+
+enum { XM_EMBED = 0, XM_REDUCE = 1, XM_HEAD_EMBED = 2 };
+enum { PH_A = 0, PH_B = 1, PH_C = 2, PH_H = 3 };
+
+struct ClArgs {
+  int B, T, ph, d, H, RC, s, L, n_in, n_out, FS16, map_dim, has_map_fusion, prof_idx;
+  const float *part_in, *xres_in;
+  float *part_out, *xres_out;
+  const float *red_bias;
+  mmt_norm red_ln;
+  mmt_dec_layer W;
+  mmt_linear input_fc, output_fc;
+  const float *pe;
+  int n_chain;                      // the small linears behind output_fc: fusion/hist_map then decoder/MLP
+  mmt_linear chain[CHAIN_MAX];
+  mmt_norm chain_ln[CHAIN_MAX];     // LayerNorm + ReLU after chain[i] when chain_ln[i].g != NULL
+  const float *start_pos, *tgt, *map_feat;
+  float *pred_st, *h_out;
+  const uint8_t *pad_mask;
+  const float *memkv;
+  float *selfkv;
+};
+
+// ------------------------------------------------------------------------------- predicated loads without branches
+// Every "load if valid, else zero" of the entry burst is a raw buffer load whose offset is pushed out of range for
+// the invalid lanes (the hardware returns 0 and fetches nothing).  With `cond ? *p : 0` the compiler builds
+// branches whose merge copies force an s_waitcnt vmcnt(0) in the middle of the burst: one memory round trip each.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x80000000, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bl4(rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float bl1(rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+// ------------------------------------------------------------------------------- K-split linear
+// Y[16][16*S] = X[16][16*K16] W^T with the K range dealt over the waves (CPW chunks of 16 each): every wave
+// requests all of its weights at once (ks_load), multiplies (ks_mfma) and leaves S partial 16x16 tiles in
+// LDS; ks_reduce sums them in wave order.
+template <int SMAX, int CPW>
+struct KsW {
+  f32x4 w[SMAX][CPW];
+};
+
+template <int SMAX, int CPW, class SlabFn>
+__device__ __forceinline__ void ks_load(KsW<SMAX, CPW> &r, const float *Wp, int K16, int S, SlabFn slab_of) {
+  const int w = wave_id();
+  const rsrc_t rs = mk_rsrc(Wp);
+  const unsigned lane_off = lane_id() * 16u;
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s)
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = w * CPW + i;
+#ifdef EXP_NOW
+      r.w[s][i] = bl4(rs, OOB);
+#else
+      r.w[s][i] = bl4(rs, (s < S && c < K16) ? (unsigned)(slab_of(s) * K16 + c) * 1024u + lane_off : OOB);
+#endif
+    }
+}
+
+template <int SMAX, int CPW>
+__device__ __forceinline__ void ks_mfma(const KsW<SMAX, CPW> &r, const float *X, int ldx, int K16, int S, float *red) {
+  const int lane = lane_id(), w = wave_id();
+  if (w * CPW >= K16) return;                       // this wave holds no chunk (not read by ks_reduce)
+  const float *xrow = X + (lane & 15) * ldx + (lane >> 4) * 4;
+  f32x4 acc[SMAX];
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int c = w * CPW + i;
+    if (c < K16) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + c * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], r.w[s][i][e], acc[s], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s)
+    if (s < S) *reinterpret_cast<f32x4 *>(red + ((w * KS_SMAX + s) * 64 + lane) * 4) = acc[s];
+}
+
+// thread -> output element of reduction pass `it`: idx = tid + CNT*it -> (row, col); col < 16*S when valid
+__device__ __forceinline__ bool ks_elem(int it, int S, int &row, int &col) {
+  const int idx = threadIdx.x + CNT * it;
+  const int s = idx >> 8, ln = (idx & 255) >> 2, r = idx & 3;
+  row = 4 * (ln >> 4) + r;
+  col = s * 16 + (ln & 15);
+  return idx < S * 256;
+}
+// epi(row, col, sum, it); NIT passes cover S <= 2*NIT slabs
+template <int CPW, int NIT, class Epi>
+__device__ __forceinline__ void ks_reduce(const float *red, int K16, int S, Epi epi) {
+  const int nwu = min(CNW, (K16 + CPW - 1) / CPW);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = threadIdx.x + CNT * it;
+    if (idx < S * 256) {
+      const int s = idx >> 8, rem = idx & 255;
+      float sum = 0.f;
+      for (int w = 0; w < nwu; ++w) sum += red[(w * KS_SMAX + s) * 256 + rem];
+      int row, col;
+      ks_elem(it, S, row, col);
+      epi(row, col, sum, it);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- N-split linear
+// part[rows][d] = X[16][16*K2] Wslice^T, Wslice = chunks [chunk0, chunk0+K2) of a packed (d x Kfull) matrix; wave w
+// owns slabs w and w+8 (d <= 256).  Results go straight from the accumulators to global memory.
+template <int NS_KMAX>
+struct NsW {
+  f32x4 w[2][NS_KMAX];
+};
+template <int NS_KMAX>
+__device__ __forceinline__ void ns_load(NsW<NS_KMAX> &r, const float *Wp, int Kfull16, int chunk0, int K2, int D16) {
+  const int w = wave_id();
+  const rsrc_t rs = mk_rsrc(Wp);
+  const unsigned lane_off = lane_id() * 16u;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int c = 0; c < NS_KMAX; ++c) {
+      const int slab = w + CNW * j;
+#ifdef EXP_NOW
+      r.w[j][c] = bl4(rs, OOB);
+#else
+      r.w[j][c] = bl4(rs, (slab < D16 && c < K2) ? (unsigned)(slab * Kfull16 + chunk0 + c) * 1024u + lane_off : OOB);
+#endif
+    }
+}
+template <int NS_KMAX>
+__device__ __forceinline__ void ns_mfma_store(const NsW<NS_KMAX> &r, const float *X, int ldx, int K2, int D16, float *part, int d,
+                                              int nrows) {
+  const int lane = lane_id(), w = wave_id();
+  const float *xrow = X + (lane & 15) * ldx + (lane >> 4) * 4;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int c = 0; c < NS_KMAX; ++c) {
+    if (c < K2) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(xrow + c * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], r.w[j][c][e], acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int slab = w + CNW * j;
+    if (slab < D16) {
+      const int col = slab * 16 + (lane & 15), row0 = (lane >> 4) * 4;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        if (row0 + rr < nrows) part[(size_t)(row0 + rr) * d + col] = acc[j][rr];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- 16-lane row reductions (DPP)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
+// ------------------------------------------------------------------------------- x = LN(res + bias + sum_g part[g])
+// 32 lanes per row, two float4 column groups per lane (d <= 256).  Summation order is fixed.
+struct RedRegs {
+  f32x4 res[2], bias[2], gam[2], bet[2], p[2][8];
+};
+__device__ __forceinline__ void reduce_issue(RedRegs &R, const ClArgs &a, int cluster) {
+  const int tid = threadIdx.x, row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
+  const rsrc_t res = mk_rsrc(a.xres_in + (size_t)cluster * 16 * a.d), pp = mk_rsrc(a.part_in + (size_t)cluster * a.H * 16 * a.d);
+  const rsrc_t rb = mk_rsrc(a.red_bias), rg = mk_rsrc(a.red_ln.g), rbt = mk_rsrc(a.red_ln.b);
+  const unsigned gstride = 16u * a.d * 4u;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = l32 + 32 * j;
+    const bool ok = q < nq && row < a.RC;
+    const unsigned ro = ok ? (unsigned)(row * a.d + 4 * q) * 4u : OOB, co = ok ? (unsigned)q * 16u : OOB;
+    R.res[j] = bl4(res, ro);
+#pragma unroll
+#ifdef EXP_NOPART
+    for (int g = 0; g < 8; ++g) R.p[j][g] = bl4(pp, OOB);
+#else
+    for (int g = 0; g < 8; ++g) R.p[j][g] = bl4(pp, (ok && g < a.H) ? g * gstride + ro : OOB);
+#endif
+    R.bias[j] = bl4(rb, co);
+    R.gam[j] = bl4(rg, co);
+    R.bet[j] = bl4(rbt, co);
+  }
+}
+__device__ __forceinline__ void reduce_finish(const RedRegs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res) {
+  const int tid = threadIdx.x, row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
+  const bool live = row < a.RC;
+  f32x4 v[2];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    f32x4 acc = R.res[j] + R.bias[j];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc += R.p[j][g];      // unused slots hold zeros
+    v[j] = acc;
+    s += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  const float mu = s / (float)a.d;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (l32 + 32 * j < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dlt = v[j][e] - mu;
+        var += dlt * dlt;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 32);
+  const float rstd = 1.0f / sqrtf(var / (float)a.d + MMT_LN_EPS);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = l32 + 32 * j;
+    if (q < nq) {
+      f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};          // rows beyond the cluster stay zero (finite MFMA operands)
+      if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mu) * rstd * R.gam[j][e] + R.bet[j][e];
+      }
+      *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = y;
+      if (write_res && live) reinterpret_cast<f32x4 *>(a.xres_out + ((size_t)cluster * 16 + row) * a.d)[q] = y;
+    }
+  }
+}
+
+// x = tok W_in^T + b + pe[s]  (Transformer_model.py:100-102); tok is a 16x16 LDS tile (n_in <= 16)
+__device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const float *tok, float *xs, int ldx, bool write_res) {
+  const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
+  const f32x4 *W4 = reinterpret_cast<const f32x4 *>(a.input_fc.w) + lane;
+  const f32x4 xv = *reinterpret_cast<const f32x4 *>(tok + (lane & 15) * LDTOK + (lane >> 4) * 4);
+  for (int slab = w; slab < D16; slab += CNW) {
+    const f32x4 wv = W4[(size_t)slab * 64];
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], wv[e], acc, 0, 0, 0);
+    const int col = slab * 16 + (lane & 15), row0 = (lane >> 4) * 4;
+    const float add = a.input_fc.b[col] + a.pe[(size_t)a.s * a.d + col];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float y = acc[rr] + add;
+      xs[(row0 + rr) * ldx + col] = y;
+      if (write_res && row0 + rr < a.RC) a.xres_out[((size_t)cluster * 16 + row0 + rr) * a.d + col] = y;
+    }
+  }
+}
+
+__device__ __forceinline__ void small_load(KsW<4, 1> &r, const mmt_linear &lin) {
+  ks_load<4, 1>(r, lin.w, round16(lin.k) >> 4, round16(lin.n) >> 4, [](int s) { return s; });
+}
+
+// what a phase requests from memory for its own sub-layer
+template <int DH, int PHASE>
+struct PhaseGeom {      // register tiles sized per phase: every load instruction of the burst is a useful one
+  static constexpr int S1MAX = PHASE == PH_A ? 3 * DH / 16 : PHASE == PH_B ? DH / 16 : 4;
+  static constexpr int K2MAX = PHASE == PH_C ? 4 : DH / 16;
+};
+template <int DH, int CPW, int PHASE>
+struct MainRegs {
+  KsW<PhaseGeom<DH, PHASE>::S1MAX, CPW> w1;
+  NsW<PhaseGeom<DH, PHASE>::K2MAX> w2;
+  float b1[3];               // bias of the first linear for this thread's reduction elements
+  f32x4 kv[DH / 4];          // K/V cache rows (whole 128-byte lines), staged into LDS later
+  int pad;                   // key-padding flag of (agent tid>>4, key tid&15), phase B
+};
+
+template <int DH, int CPW, int PHASE>
+__device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const ClArgs &a, int a0, int na, int g) {
+  const int d = a.d, D16 = d >> 4, K16 = D16;
+  constexpr int S_A = 3 * DH / 16, S_B = DH / 16;
+  if constexpr (PHASE == PH_A) {
+    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.W.qkv.w, K16, S_A, [&](int s) { return (s / S_B) * D16 + g * S_B + (s % S_B); });
+  } else if constexpr (PHASE == PH_B) {
+    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.W.cq.w, K16, S_B, [&](int s) { return g * S_B + s; });
+  } else {
+    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.W.ff1.w, K16, a.FS16, [&](int s) { return g * a.FS16 + s; });
+  }
+  const int S1 = PHASE == PH_A ? S_A : PHASE == PH_B ? S_B : a.FS16;
+  const rsrc_t rb1 = mk_rsrc(PHASE == PH_A ? a.W.qkv.b : PHASE == PH_B ? a.W.cq.b : a.W.ff1.b);
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    int row, col;
+    const bool ok = ks_elem(it, S1, row, col);
+    int bi;
+    if constexpr (PHASE == PH_A) bi = (col / DH) * d + g * DH + (col % DH);
+    else if constexpr (PHASE == PH_B) bi = g * DH + col;
+    else bi = g * a.FS16 * 16 + col;
+    M.b1[it] = bl1(rb1, ok ? (unsigned)bi * 4u : OOB);
+  }
+  if constexpr (PHASE == PH_A || PHASE == PH_B) {
+    // unit u -> (agent, key, k|v, 16-byte piece): the DH/4 lanes of a row read one contiguous 4*DH-byte line
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+    const int rows_per_agent = 2 * nglob, total = na * rows_per_agent * (DH / 4);
+    const float *base = PHASE == PH_A ? a.selfkv + (((size_t)a.L * a.B + a0) * a.ph) * 2 * d
+                                      : a.memkv + (((size_t)a.L * a.B + a0) * a.T) * 2 * d;
+    const unsigned astride = (unsigned)(PHASE == PH_A ? a.ph : a.T) * 2 * d;
+    const rsrc_t rkv = mk_rsrc(base);
+    const int rpa = max(rows_per_agent, 1);
+#pragma unroll
+    for (int it = 0; it < DH / 4; ++it) {
+      const int u = threadIdx.x + CNT * it;
+      const int c4 = u % (DH / 4), row = u / (DH / 4), ag = row / rpa, rem = row - ag * rpa;
+      const int j = rem >> 1, kv = rem & 1;
+      M.kv[it] = bl4(rkv, u < total ? (ag * astride + (unsigned)j * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+    }
+  }
+  M.pad = 0;
+  if constexpr (PHASE == PH_B) {
+    const int ar = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && threadIdx.x < 256 && ar < na && l16 < a.T)
+                                                    ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
+  }
+  if constexpr (PHASE == PH_A) ns_load(M.w2, a.W.out.w, K16, g * S_B, S_B, D16);
+  else if constexpr (PHASE == PH_B) ns_load(M.w2, a.W.cout.w, K16, g * S_B, S_B, D16);
+  else ns_load(M.w2, a.W.ff2.w, a.H * a.FS16, g * a.FS16, a.FS16, D16);
+}
+
+template <int DH, int CPW, int PHASE, int XMODE>
+__global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  const int d = a.d, ldx = d + MMT_PAD, D16 = d >> 4, K16 = D16;
+  constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
+  constexpr int LDK = DH + 4;                    // K/V staging row stride: conflict-free b128 reads per 16-lane group
+  float *xs = smem;                              // [16][ldx]   LayerNorm'ed input of this sub-layer
+  float *red = xs + 16 * ldx;                    // [8][KS_SMAX][256] K-split partial tiles
+  float *t1 = red + CNW * KS_SMAX * 256;         // [16][LD1]   q|k|v of the head, or the FFN hidden slice
+  float *ob = t1 + 16 * LD1;                     // [16][LDO]   attention output of the head
+  float *ha = ob + 16 * LDO;                     // [16][LDO]   head-MLP ping
+  float *hb = ha + 16 * LDO;                     // [16][LDO]   head-MLP pong
+  float *tok = hb + 16 * LDO;                    // [16][LDTOK] token fed to input_fc
+  float *ps = tok + 16 * LDTOK;                  // [16][16]    attention probabilities
+  float *Vs = ps + 256;                          // [16][KMAX][LDK]   (phases A, B only)
+  float *Ks = red;                               // [16][KMAX][LDK]   reuses the partial-tile region once it is summed
+  static_assert(16 * KMAX * LDK <= CNW * KS_SMAX * 256, "K staging must fit the reduction scratch");
+  const int tid = threadIdx.x;
+  const int G = PHASE == PH_H ? 1 : a.H;
+  const int cluster = blockIdx.x / G, g = blockIdx.x - cluster * G;
+  const int a0 = cluster * a.RC, na = min(a.RC, a.B - a0);
+  constexpr int S_A = 3 * DH / 16, S_B = DH / 16;
+  constexpr bool HEAD = PHASE == PH_H || (PHASE == PH_A && XMODE == XM_HEAD_EMBED);
+  constexpr bool REDUCES = !(PHASE == PH_A && XMODE == XM_EMBED);
+
+  CSTAMP(0);
+  // ---- 1. one burst of requests: what the previous launch produced first, then this workgroup's own operands
+  RedRegs R;                                        // deliberately not initialised: only waves with rows < RC touch it
+  const bool red_wave = REDUCES && wave_id() * 2 < a.RC;   // wave-uniform (RC is even): idle waves issue nothing
+  if (red_wave) reduce_issue(R, a, cluster);
+  MainRegs<DH, CPW, PHASE> M = {};
+  KsW<4, CPW> wo = {};
+  KsW<4, 1> sm_cur = {};
+  if constexpr (HEAD) {
+    ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });
+    if (!a.tgt) small_load(sm_cur, a.chain[0]);
+  } else {
+    main_issue<DH, CPW, PHASE>(M, a, a0, na, g);     // (behind the head when there is one: its registers are busy)
+  }
+  CSTAMP(1);
+  for (int i = tid; i < 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256; i += CNT) t1[i] = 0.f;
+  __syncthreads();
+
+  // ---- 2. input of this sub-layer
+  if (red_wave) reduce_finish(R, a, cluster, xs, ldx, g == 0 && !HEAD);
+  else if (REDUCES) {                               // rows beyond the cluster: zeros (finite MFMA operands)
+    const int row = tid >> 5, l32 = tid & 31;
+    for (int q = l32; q < (d >> 2); q += 32) *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (HEAD) {
+    // head of step hs = s - 1: output_fc -> [fusion/hist_map] -> decoder/MLP -> position feedback (mgcvae.py:435-446)
+    const int hs = a.s - 1;
+    __syncthreads();
+    const int So = round16(a.n_out) >> 4;
+    ks_mfma<4, CPW>(wo, xs, ldx, K16, So, red);
+    if (!a.tgt && a.has_map_fusion)
+      for (int i = tid; i < na * a.map_dim; i += CNT) {
+        const int r = i / a.map_dim, c = i - r * a.map_dim;
+        ha[r * LDO + a.n_out + c] = a.map_feat[(size_t)(a0 + r) * a.map_dim + c];
+      }
+    __syncthreads();
+    ks_reduce<CPW, 2>(red, K16, So, [&](int r, int c, float v, int) {
+      if (c < a.n_out) {
+        v += a.output_fc.b[c];
+        ha[r * LDO + c] = v;
+        if (g == 0 && a.h_out && r < na) a.h_out[((size_t)(a0 + r) * a.ph + hs) * a.n_out + c] = v;
+      }
+    });
+    __syncthreads();
+    if (!a.tgt) {
+      float *cur = ha, *alt = hb;
+#pragma unroll
+      for (int i = 0; i < CHAIN_MAX; ++i) {
+        if (i < a.n_chain) {
+          KsW<4, 1> sm_nxt = sm_cur;
+          if (i + 1 < CHAIN_MAX && i + 1 < a.n_chain) small_load(sm_nxt, a.chain[i + 1 < CHAIN_MAX ? i + 1 : i]);
+          const int k16 = round16(a.chain[i].k) >> 4, s16 = round16(a.chain[i].n) >> 4, n = a.chain[i].n;
+          const float *bias = a.chain[i].b;
+          ks_mfma<4, 1>(sm_cur, cur, LDO, k16, s16, red);
+          __syncthreads();
+          ks_reduce<1, 2>(red, k16, s16, [&](int r, int c, float v, int) { alt[r * LDO + c] = c < n ? v + (bias ? bias[c] : 0.f) : 0.f; });
+          __syncthreads();
+          if (a.chain_ln[i].g) {
+            layer_norm_rows<true>(alt, LDO, 16, n, a.chain_ln[i]);
+            __syncthreads();
+          }
+          float *t = cur;
+          cur = alt;
+          alt = t;
+          sm_cur = sm_nxt;
+        }
+      }
+      // cur holds delta (n_in columns)
+      for (int i = tid; i < na * a.n_in; i += CNT) {
+        const int r = i / a.n_in, c = i - r * a.n_in;
+        const float prev = hs == 0 ? a.start_pos[(size_t)(a0 + r) * a.n_in + c]
+                                   : a.pred_st[((size_t)(a0 + r) * a.ph + hs - 1) * a.n_in + c];
+        const float np = prev + cur[r * LDO + c];
+        tok[r * LDTOK + c] = np;
+        if (g == 0) a.pred_st[((size_t)(a0 + r) * a.ph + hs) * a.n_in + c] = np;
+      }
+    }
+    if constexpr (PHASE == PH_H) return;
+    main_issue<DH, CPW, PHASE>(M, a, a0, na, g);
+    __syncthreads();
+  }
+  if constexpr (PHASE == PH_H) return;
+  if constexpr (PHASE == PH_A && XMODE != XM_REDUCE) {
+    if (a.tgt || XMODE == XM_EMBED)
+      for (int i = tid; i < na * a.n_in; i += CNT) {
+        const int r = i / a.n_in, c = i - r * a.n_in;
+        tok[r * LDTOK + c] = a.tgt ? a.tgt[((size_t)(a0 + r) * a.ph + a.s) * a.n_in + c]
+                                   : a.start_pos[(size_t)(a0 + r) * a.n_in + c];
+      }
+    __syncthreads();
+    embed_token(a, cluster, tok, xs, ldx, g == 0);
+  }
+  __syncthreads();
+
+  CSTAMP(2);
+  // ---- 3. first linear (K-split over the waves), bias (+ReLU) in the reduction
+  const int S1 = PHASE == PH_A ? S_A : PHASE == PH_B ? S_B : a.FS16;
+  ks_mfma<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, xs, ldx, K16, S1, red);
+  __syncthreads();
+  ks_reduce<CPW, 3>(red, K16, S1, [&](int r, int c, float v, int it) {
+    v += M.b1[it];
+    if (PHASE == PH_C) v = fmaxf(v, 0.f);
+    t1[r * LD1 + c] = v;
+  });
+  CSTAMP(3);
+
+  // ---- 4. attention of head g for the agents of the cluster, K/V staged in LDS
+  const float *x2 = t1;
+  int ld2 = LD1, K2 = a.FS16;
+  if constexpr (PHASE == PH_A || PHASE == PH_B) {
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+    const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
+    __syncthreads();       // every wave is done reading `red`
+    {
+      const int rows_per_agent = 2 * nglob, total = na * rows_per_agent * (DH / 4);
+#pragma unroll
+      for (int it = 0; it < DH / 4; ++it) {
+        const int u = tid + CNT * it;
+        if (u < total) {
+          const int c4 = u % (DH / 4), row = u / (DH / 4), ag = row / rows_per_agent, rem = row - ag * rows_per_agent;
+          *reinterpret_cast<f32x4 *>(((rem & 1) ? Vs : Ks) + (ag * KMAX + (rem >> 1)) * LDK + 4 * c4) = M.kv[it];
+        }
+      }
+    }
+    __syncthreads();       // t1 (q | k | v) complete
+    if constexpr (PHASE == PH_A) {   // the new key / value: into the cache (read by later launches) and the staging tiles
+      for (int i = tid; i < na * 2 * (DH / 4); i += CNT) {
+        const int r = i / (2 * (DH / 4)), rem = i - r * 2 * (DH / 4), kv = rem / (DH / 4), c4 = rem - kv * (DH / 4);
+        const f32x4 val = *reinterpret_cast<const f32x4 *>(t1 + r * LD1 + (1 + kv) * DH + 4 * c4);
+        *reinterpret_cast<f32x4 *>(a.selfkv + (((size_t)a.L * a.B + a0 + r) * a.ph + a.s) * 2 * d + kv * d + g * DH + 4 * c4) = val;
+        *reinterpret_cast<f32x4 *>((kv ? Vs : Ks) + (r * KMAX + a.s) * LDK + 4 * c4) = val;
+      }
+      __syncthreads();
+    }
+    const int ar = tid >> 4, l16 = tid & 15;
+    if (tid < 256) {
+      float sc = -INFINITY;
+      bool masked = ar >= na || l16 >= nkeys;
+      if constexpr (PHASE == PH_B) masked = masked || M.pad != 0;
+      if (!masked) {
+        const float *q = t1 + ar * LD1, *k = Ks + (ar * KMAX + l16) * LDK;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) {
+          const f32x4 qv = *reinterpret_cast<const f32x4 *>(q + 4 * c), kv4 = *reinterpret_cast<const f32x4 *>(k + 4 * c);
+          acc = fmaf(qv[0], kv4[0], acc);
+          acc = fmaf(qv[1], kv4[1], acc);
+          acc = fmaf(qv[2], kv4[2], acc);
+          acc = fmaf(qv[3], kv4[3], acc);
+        }
+        sc = acc * (1.0f / sqrtf((float)DH));
+      }
+      const float mx = row16_max(sc);
+      float p = mx > -INFINITY ? expf(sc - mx) : 0.f;    // a fully masked row yields zeros (reference: undefined / NaN)
+      const float sum = row16_sum(p);
+      p *= sum > 0.f ? 1.0f / sum : 0.f;
+      ps[ar * 16 + l16] = p;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      constexpr int DPL = DH / 16;
+      float o[DPL];
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+      const int nk = ar < na ? nkeys : 0;
+      for (int j = 0; j < nk; ++j) {
+        const float pj = ps[ar * 16 + j];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, Vs[(ar * KMAX + j) * LDK + l16 * DPL + e], o[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) ob[ar * LDO + l16 * DPL + e] = o[e];
+    }
+    x2 = ob;
+    ld2 = LDO;
+    K2 = S_B;
+  }
+  __syncthreads();
+  CSTAMP(4);
+
+  // ---- 5. K-slice of the output projection: partial [RC][d] of this workgroup
+  ns_mfma_store(M.w2, x2, ld2, K2, D16, a.part_out + ((size_t)cluster * a.H + g) * 16 * d, d, a.RC);
+  CSTAMP(5);
+}
+
+// ------------------------------------------------------------------------------- prologue kernels
+struct CkvArgs {
+  int rows, d, L, B, T, ldx, ldb;
+  const float *src;          // (rows, d): memory or fused memory
+  float *memkv;              // [L][rows][2d]
+  mmt_linear ckv[MMT_MAX_LAYERS];
+};
+// cross-attention K/V of every layer (computed once per decode; the reference redoes it every step)
+__global__ __launch_bounds__(CNT) void mmt_dec_ckv_kernel(CkvArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float *xs = smem, *buf = xs + 16 * a.ldx;
+  const int tid = threadIdx.x, d = a.d, L = blockIdx.y;
+  const int r0 = blockIdx.x * 16, nr = min(16, a.rows - r0);
+  for (int i = tid; i < 16 * (a.ldx + a.ldb); i += CNT) smem[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < nr * (d >> 2); i += CNT) {
+    const int r = i / (d >> 2), c4 = i - r * (d >> 2);
+    *reinterpret_cast<f32x4 *>(xs + r * a.ldx + 4 * c4) = reinterpret_cast<const f32x4 *>(a.src + (size_t)(r0 + r) * d)[c4];
+  }
+  __syncthreads();
+  linear_to_lds<1, EPI_STORE>(xs, a.ldx, a.ckv[L], buf, a.ldb);
+  __syncthreads();
+  float *dst = a.memkv + ((size_t)L * a.rows + r0) * 2 * d;
+  for (int i = tid; i < nr * (d >> 1); i += CNT) {
+    const int r = i / (d >> 1), c4 = i - r * (d >> 1);
+    reinterpret_cast<f32x4 *>(dst + (size_t)r * 2 * d)[c4] = *reinterpret_cast<const f32x4 *>(buf + r * a.ldb + 4 * c4);
+  }
+}
+
+struct FuseArgs {
+  int rows, d, T, mf, ld;
+  const float *memory, *mem_feat;
+  float *fused;
+  mmt_mlp M;
+};
+// fusion/lane_hist (or mix_fc) on cat[memory, lane feature repeated over T]   (mgcvae.py:404-409)
+__global__ __launch_bounds__(CNT) void mmt_dec_fuse_kernel(FuseArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  float *ra = smem, *rb = ra + 16 * a.ld, *out = rb + 16 * a.ld;
+  const int tid = threadIdx.x, d = a.d, mf = a.mf;
+  const int r0 = blockIdx.x * 16, nr = min(16, a.rows - r0);
+  for (int i = tid; i < 16 * 3 * a.ld; i += CNT) smem[i] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < nr * (d + mf); i += CNT) {
+    const int r = i / (d + mf), c = i - r * (d + mf);
+    ra[r * a.ld + c] = c < d ? a.memory[(size_t)(r0 + r) * d + c] : a.mem_feat[(size_t)((r0 + r) / a.T) * mf + (c - d)];
+  }
+  __syncthreads();
+  mlp_stack_tile(a.M, ra, rb, a.ld, out, a.ld, nr);
+  for (int i = tid; i < nr * d; i += CNT) {
+    const int r = i / d, c = i - r * d;
+    a.fused[(size_t)(r0 + r) * d + c] = out[r * a.ld + c];
+  }
+}
+
+int mlp_width(const mmt_mlp &m) {
+  int w = std::max(m.out.k, m.out.n);
+  for (int i = 0; i < m.n_hidden; ++i) w = std::max(w, std::max(m.hidden[i].k, m.hidden[i].n));
+  return w;
+}
+
+// Agents per cluster: 16 fills the MFMA tile; small batches use fewer so that more CUs share the work (every
+// workgroup takes in its weight slice at ~50 GB/s, and the partials it sums scale with the rows).
+int cluster_rows(int B, int H) {
+  if (const char *e = getenv("MMT_CLUSTER_ROWS")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8 || v == 16) return v;
+  }
+  int dev = 0, ncu = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  int rc = 16;
+  while (rc > 4 && ((B + rc / 2 - 1) / (rc / 2)) * H <= ncu) rc /= 2;
+  return rc;
+}
+
+}  // namespace
+
+// Geometry the cluster kernels are written for; anything else runs on the persistent kernel.
+bool mmt_cluster_decoder_supports(const mmt_decoder *dec, int map_dim, bool autoregressive, int T, int ph) {
+  const int d = dec->d_model, H = dec->nhead;
+  if (d % 16 || d > 256 || H < 1 || H > 8 || d % H) return false;
+  const int dh = d / H;
+  if (dh != 16 && dh != 32) return false;
+  if (T > KMAX || ph > KMAX) return false;
+  if (dec->d_ff % (16 * H) || dec->d_ff / H > 64) return false;
+  if (dec->n_out < 1 || dec->n_out > 64 || dec->n_in < 1 || dec->n_in > 16) return false;
+  if (autoregressive) {
+    if (dec->head.n_hidden + 1 + (dec->has_map_fusion ? dec->map_fusion.n_hidden + 1 : 0) > CHAIN_MAX) return false;
+    if (mlp_width(dec->head) > 64) return false;
+    if (dec->has_map_fusion && (mlp_width(dec->map_fusion) > 64 || dec->n_out + map_dim > 64)) return false;
+  }
+  return true;
+}
+
+size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
+  const int RC = cluster_rows(B, dec->nhead);
+  const size_t NC = (B + RC - 1) / RC, d = dec->d_model;
+  return NC * 16 * d * (2 * (size_t)dec->nhead + 2) + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64;
+}
+
+#define CL_CHECK(what)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = hipGetLastError();                                                     \
+    if (e_ != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+template <int DH, int CPW>
+static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], hipStream_t st) {
+  const int d = dec->d_model, H = dec->nhead, NC = (B + a.RC - 1) / a.RC, L = dec->nlayers;
+  constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
+  const size_t lds_c = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256) * sizeof(float);
+  const size_t lds_a = lds_c + (size_t)16 * KMAX * (DH + 4) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+#define SET_LDS(PHASE, XM, BYTES) \
+  (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
+    SET_LDS(PH_A, XM_EMBED, lds_a);
+    SET_LDS(PH_A, XM_REDUCE, lds_a);
+    SET_LDS(PH_A, XM_HEAD_EMBED, lds_a);
+    SET_LDS(PH_B, XM_REDUCE, lds_a);
+    SET_LDS(PH_C, XM_REDUCE, lds_c);
+    SET_LDS(PH_H, XM_REDUCE, lds_c);
+#undef SET_LDS
+    attr_done = true;
+  }
+  int p = 0;   // phase counter: phase p writes part[p&1] / xres[p&1] and reads the other pair
+  auto bufs = [&](ClArgs &x) {
+    x.part_out = part[p & 1];
+    x.xres_out = xres[p & 1];
+    x.part_in = part[(p + 1) & 1];
+    x.xres_in = xres[(p + 1) & 1];
+    x.prof_idx = p;
+    ++p;
+  };
+  const mmt_dec_layer &last = dec->layer[L - 1];
+  const dim3 grid(NC * H), blk(CNT);
+  for (int s = 0; s < ph; ++s) {
+    a.s = s;
+    for (int l = 0; l < L; ++l) {
+      a.L = l;
+      a.W = dec->layer[l];
+      const mmt_dec_layer &prev = l == 0 ? last : dec->layer[l - 1];
+      a.red_bias = prev.ff2.b;
+      a.red_ln = prev.ln3;
+      bufs(a);
+      if (l > 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_REDUCE>), grid, blk, lds_a, st, a);
+      else if (s == 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_EMBED>), grid, blk, lds_a, st, a);
+      else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_HEAD_EMBED>), grid, blk, lds_a, st, a);
+      a.red_bias = a.W.out.b;
+      a.red_ln = a.W.ln1;
+      bufs(a);
+      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_B, XM_REDUCE>), grid, blk, lds_a, st, a);
+      a.red_bias = a.W.cout.b;
+      a.red_ln = a.W.ln2;
+      bufs(a);
+      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_C, XM_REDUCE>), grid, blk, lds_c, st, a);
+    }
+  }
+  a.s = ph;
+  a.red_bias = last.ff2.b;
+  a.red_ln = last.ln3;
+  bufs(a);
+  hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_H, XM_REDUCE>), dim3(NC), blk, lds_c, st, a);
+  CL_CHECK("mmt_decoder_forward (cluster phases)");
+  return MMT_OK;
+}
+
+// Same contract as mmt_decoder_forward (arguments already validated there).
+int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
+                                const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
+                                const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
+                                void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int d = dec->d_model, H = dec->nhead, L = dec->nlayers;
+  const int RC = cluster_rows(B, H), NC = (B + RC - 1) / RC;
+  float *memkv = workspace;
+  float *selfkv = memkv + (size_t)L * B * T * 2 * d;
+  float *extra = selfkv + (size_t)L * B * ph * 2 * d;
+  float *part[2], *xres[2];
+  part[0] = extra;
+  part[1] = part[0] + (size_t)NC * H * 16 * d;
+  xres[0] = part[1] + (size_t)NC * H * 16 * d;
+  xres[1] = xres[0] + (size_t)NC * 16 * d;
+  float *fused = xres[1] + (size_t)NC * 16 * d;
+
+  const float *src = memory;
+  const int rows = B * T;
+  if (dec->has_mem_fusion) {
+    FuseArgs f;
+    f.rows = rows;
+    f.d = d;
+    f.T = T;
+    f.mf = mem_feat_dim;
+    f.ld = ((std::max(mlp_width(dec->mem_fusion), d + mem_feat_dim) + 15) & ~15) + MMT_PAD;
+    f.memory = memory;
+    f.mem_feat = mem_feat;
+    f.fused = fused;
+    f.M = dec->mem_fusion;
+    const size_t lds = (size_t)16 * 3 * f.ld * sizeof(float);
+    if (lds > 160 * 1024) return mmt_set_error(MMT_EINVAL, "mmt_decoder_forward: memory fusion tile needs %zu B of LDS", lds);
+    (void)hipFuncSetAttribute((const void *)mmt_dec_fuse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(mmt_dec_fuse_kernel, dim3((rows + 15) / 16), dim3(CNT), lds, st, f);
+    CL_CHECK("mmt_decoder_forward (memory fusion)");
+    src = fused;
+  }
+  {
+    CkvArgs c;
+    c.rows = rows;
+    c.d = d;
+    c.L = L;
+    c.B = B;
+    c.T = T;
+    c.ldx = d + MMT_PAD;
+    c.ldb = 2 * d + MMT_PAD;
+    c.src = src;
+    c.memkv = memkv;
+    for (int l = 0; l < L; ++l) c.ckv[l] = dec->layer[l].ckv;
+    const size_t lds = (size_t)16 * (c.ldx + c.ldb) * sizeof(float);
+    hipLaunchKernelGGL(mmt_dec_ckv_kernel, dim3((rows + 15) / 16, L), dim3(CNT), lds, st, c);
+    CL_CHECK("mmt_decoder_forward (cross K/V)");
+  }
+  ClArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B;
+  a.T = T;
+  a.ph = ph;
+  a.d = d;
+  a.H = H;
+  a.RC = RC;
+  a.n_in = dec->n_in;
+  a.n_out = dec->n_out;
+  a.FS16 = dec->d_ff / H / 16;
+  a.map_dim = map_dim;
+  a.has_map_fusion = (!tgt && dec->has_map_fusion) ? 1 : 0;
+  a.input_fc = dec->input_fc;
+  a.output_fc = dec->output_fc;
+  a.pe = dec->pe;
+  if (!tgt) {
+    auto push = [&](const mmt_mlp &M) {
+      for (int i = 0; i < M.n_hidden; ++i) {
+        a.chain[a.n_chain] = M.hidden[i];
+        a.chain_ln[a.n_chain++] = M.hidden_ln[i];
+      }
+      a.chain[a.n_chain++] = M.out;       // chain_ln stays NULL: no LayerNorm after an Mlp's last Linear
+    };
+    if (dec->has_map_fusion) push(dec->map_fusion);
+    push(dec->head);
+  }
+  a.start_pos = start_pos;
+  a.tgt = tgt;
+  a.map_feat = map_feat;
+  a.pred_st = pred_st;
+  a.h_out = h_out;
+  a.pad_mask = pad_mask;
+  a.memkv = memkv;
+  a.selfkv = selfkv;
+  const int dh = d / H;
+  const bool cpw2 = d > 128;
+  if (dh == 32) return cpw2 ? launch_phases<32, 2>(dec, a, B, ph, part, xres, st) : launch_phases<32, 1>(dec, a, B, ph, part, xres, st);
+  return cpw2 ? launch_phases<16, 2>(dec, a, B, ph, part, xres, st) : launch_phases<16, 1>(dec, a, B, ph, part, xres, st);
+}

@@ -279,6 +279,22 @@ __device__ __forceinline__ void layer_norm_rows_to(const float *S, int lds, floa
   }
 }
 
+// n_hidden x (Linear, LN, ReLU) + Linear on a 16-row LDS tile; cur/alt are ping-pong regions.
+__device__ __forceinline__ void mlp_stack_tile(const mmt_mlp &M, float *cur, float *alt, int ld, float *out,
+                                               int ldout, int nrows) {
+  for (int i = 0; i < M.n_hidden; ++i) {
+    linear_to_lds<1, EPI_STORE>(cur, ld, M.hidden[i], alt, ld);
+    __syncthreads();
+    layer_norm_rows<true>(alt, ld, nrows, M.hidden[i].n, M.hidden_ln[i]);
+    __syncthreads();
+    float *t = cur;
+    cur = alt;
+    alt = t;
+  }
+  linear_to_lds<1, EPI_STORE>(cur, ld, M.out, out, ldout);
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // One attention "group" = 16 lanes serving one (query row, head); DH = head dim (16, 32 or 64).
 //   q      : pointer to the query's head slice (DH floats, LDS)

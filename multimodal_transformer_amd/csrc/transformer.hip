@@ -135,22 +135,6 @@ struct DecLaunch {
   int map_dim, mem_feat_dim;
 };
 
-// n_hidden x (Linear, LN, ReLU) + Linear on a 16-row LDS tile; cur/alt are ping-pong regions.
-__device__ __forceinline__ void mlp_stack_tile(const mmt_mlp &M, float *cur, float *alt, int ld, float *out,
-                                               int ldout, int nrows) {
-  for (int i = 0; i < M.n_hidden; ++i) {
-    linear_to_lds<1, EPI_STORE>(cur, ld, M.hidden[i], alt, ld);
-    __syncthreads();
-    layer_norm_rows<true>(alt, ld, nrows, M.hidden[i].n, M.hidden_ln[i]);
-    __syncthreads();
-    float *t = cur;
-    cur = alt;
-    alt = t;
-  }
-  linear_to_lds<1, EPI_STORE>(cur, ld, M.out, out, ldout);
-  __syncthreads();
-}
-
 template <int DH>
 __global__ __launch_bounds__(MMT_NT) void mmt_decoder_kernel(mmt_decoder D, DecLaunch P, const float *__restrict__ memory,
                                                           const uint8_t *__restrict__ pad_mask,
@@ -480,9 +464,25 @@ extern "C" int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, in
   return check_launch("mmt_encoder_forward");
 }
 
+// decoder_cluster.hip
+bool mmt_cluster_decoder_supports(const mmt_decoder *dec, int map_dim, bool autoregressive, int T, int ph);
+size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T);
+int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
+                                const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
+                                const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
+                                void *stream);
+
+static int g_decoder_impl = MMT_DECODER_AUTO;
+extern "C" int mmt_decoder_select(int impl) {
+  if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER)
+    return fail(MMT_EINVAL, "mmt_decoder_select: unknown implementation %d", impl);
+  g_decoder_impl = impl;
+  return MMT_OK;
+}
+
 extern "C" size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph) {
   if (!dec || B <= 0 || T <= 0 || ph <= 0) return 0;
-  return (size_t)dec->nlayers * B * (size_t)(T + ph) * 2 * dec->d_model;
+  return (size_t)dec->nlayers * B * (size_t)(T + ph) * 2 * dec->d_model + mmt_cluster_decoder_extra_floats(dec, B, T);
 }
 
 extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
@@ -501,6 +501,10 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   if (dec->has_map_fusion && !tgt && (!map_feat || map_dim <= 0)) return fail(MMT_EINVAL, "mmt_decoder_forward: map fusion configured but no map_feat");
   if (dec->has_mem_fusion && (!mem_feat || mem_feat_dim <= 0)) return fail(MMT_EINVAL, "mmt_decoder_forward: memory fusion configured but no mem_feat");
   const int d = dec->d_model;
+  const bool cluster_ok = mmt_cluster_decoder_supports(dec, map_dim, tgt == nullptr, T, ph);
+  if (g_decoder_impl == MMT_DECODER_CLUSTER && !cluster_ok)
+    return fail(MMT_EINVAL, "mmt_decoder_forward: the cluster decoder does not support this geometry (d=%d H=%d f=%d)", d,
+                dec->nhead, dec->d_ff);
   int small = max_mlp_width(dec->head);
   small = std::max(small, (dec->n_out + 15) & ~15);
   if (dec->has_map_fusion) {
@@ -516,6 +520,18 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
     if (kin != d + mem_feat_dim) return fail(MMT_EINVAL, "mmt_decoder_forward: memory fusion expects %d inputs, got d+mem_feat_dim=%d", kin, d + mem_feat_dim);
     if (dec->mem_fusion.out.n != d) return fail(MMT_EINVAL, "mmt_decoder_forward: memory fusion must output d_model");
   }
+  // AUTO: the cluster kernels win while one cluster round fits the chip (16 agents x nhead workgroups each, <= #CUs
+  // workgroups: B <= 512 at 8 heads on MI355X); beyond that the persistent kernel's larger tiles are faster.
+  bool use_cluster = cluster_ok && g_decoder_impl != MMT_DECODER_PERSISTENT;
+  if (use_cluster && g_decoder_impl == MMT_DECODER_AUTO) {
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    use_cluster = ((B + 15) / 16) * dec->nhead <= ncu;
+  }
+  if (use_cluster)
+    return mmt_cluster_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T,
+                                       ph, pred_st, h_out, workspace, stream);
   // buf = [ region A | region B ], region B additionally split in two for the map-fusion ping-pong
   const int half = std::max((3 * d + 1) / 2, 2 * (small + MMT_PAD));
   const int halfr = (half + 15) & ~15;

@@ -399,6 +399,14 @@ def encoder_forward(enc: PackedEncoder, x_st: torch.Tensor, want_mask: bool = Tr
     return memory, pad
 
 
+def decoder_select(impl: str = "auto"):
+    """Choose the kernel family behind ``decoder_forward``: "auto" | "persistent" | "cluster" (include/mmt_amd.h)."""
+    table = {"auto": _lib.MMT_DECODER_AUTO, "persistent": _lib.MMT_DECODER_PERSISTENT, "cluster": _lib.MMT_DECODER_CLUSTER}
+    if impl not in table:
+        raise MmtError(f"decoder_select: unknown implementation {impl!r}")
+    _lib.check(_lib.load().mmt_decoder_select(table[impl]), "mmt_decoder_select")
+
+
 _ws_cache = {}
 
 

@@ -17,6 +17,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["auto", "persistent"])
+def decoder_impl(request):
+    """Every test runs on both decoder kernel families (include/mmt_amd.h: mmt_decoder_select): "auto" takes the
+    cluster kernels wherever their geometry allows (d <= 256, <= 16 keys), "persistent" forces the one-launch kernel."""
+    from multimodal_transformer_amd import ops
+    ops.decoder_select(request.param)
+    yield request.param
+    ops.decoder_select("auto")
+
+
 class _Env:
     robot_type = None
 
