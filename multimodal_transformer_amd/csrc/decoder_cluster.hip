@@ -18,6 +18,7 @@
 // The head (output_fc, optional map fusion, decoder MLP, position feedback) and the embedding of the next
 // token ride at the front of the next step's first phase A.
 #include "mmt_device.cuh"
+#include "mmt_gfx950.cuh"
 
 #include <algorithm>
 #include <cstdlib>
@@ -69,22 +70,6 @@ struct ClArgs {
   const float *memkv;
   float *selfkv;
 };
-
-// ------------------------------------------------------------------------------- predicated loads without branches
-// Every "load if valid, else zero" of the entry burst is a raw buffer load whose offset is pushed out of range for
-// the invalid lanes (the hardware returns 0 and fetches nothing).  With `cond ? *p : 0` the compiler builds
-// branches whose merge copies force an s_waitcnt vmcnt(0) in the middle of the burst: one memory round trip each.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr unsigned OOB = 0xFFFFFFF0u;
-__device__ __forceinline__ rsrc_t mk_rsrc(const void *p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x80000000, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bl4(rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ float bl1(rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
-}
 
 // ------------------------------------------------------------------------------- K-split linear
 // Y[16][16*S] = X[16][16*K16] W^T with the K range dealt over the waves (CPW chunks of 16 each): every wave
@@ -213,27 +198,6 @@ __device__ __forceinline__ void ns_mfma_store(const NsW<NS_KMAX> &r, const float
         if (row0 + rr < nrows) part[(size_t)(row0 + rr) * d + col] = acc[j][rr];
     }
   }
-}
-
-// ------------------------------------------------------------------------------- 16-lane row reductions (DPP)
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-// quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  v = fmaxf(v, dpp_mov<0x140>(v));
-  return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  v += dpp_mov<0x140>(v);
-  return v;
 }
 
 // ------------------------------------------------------------------------------- x = LN(res + bias + sum_g part[g])

@@ -10,7 +10,7 @@
 #include <stdint.h>
 #include "../../include/mmt_amd.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "mmt_gfx950.cuh"
 
 #define MMT_LN_EPS 1e-5f
 #define MMT_PAD 8   // row padding (floats) that makes the ds_read_b128 A-operand reads conflict free

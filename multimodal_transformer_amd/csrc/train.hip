@@ -21,9 +21,135 @@
 
 int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "mmt_gfx950.cuh"
 
 namespace {
+
+// ------------------------------------------------------------------------------------------ panel GEMM
+// The GEMMs of a training step are many and small (M = 128 rows per decoder step, K = 256..512) or tall in K (weight
+// gradients: K = ph*B rows).  BT x BT output tile per workgroup, K walked in 64-deep panels: the next panel's global
+// loads (16-byte, branch-free, predicated by out-of-range buffer offsets) are in flight while the current one is
+// multiplied out of LDS, one barrier per panel.  An operand whose unit stride is K ("KC") sits in LDS as [row][k]
+// and feeds the MFMA with one ds_read_b128; one whose unit stride is the row index sits as [k][row] and feeds it
+// with four conflict-free ds_read_b32.  Covers X W^T (KC,KC), dY W (KC,rows) and dY^T X (rows,rows).
+template <int BT, bool AK, bool BK>
+__global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
+  constexpr int KC = 64, LDK = KC + 4, LDR = BT + 4;
+  constexpr int ASZ = AK ? BT * LDK : KC * LDR, BSZ = BK ? BT * LDK : KC * LDR;
+  constexpr int NI = BT / 16;      // 16-byte loads per thread per operand per panel
+  constexpr int WT = BT / 32;      // 16x16 MFMA tiles per wave per dimension
+  constexpr int R4 = BT / 4;
+  extern __shared__ __align__(16) float smem[];
+  float *As = smem, *Bs = smem + 2 * ASZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
+  const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
+  f32x4 ar[NI], br[NI];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      if (AK) {
+        const int gm = m0 + (tid >> 4) + 16 * it, gk = k0 + 4 * (tid & 15);
+        ar[it] = bl4(ra, (gm < g.M && gk < g.K) ? (unsigned)(gm * (int)g.sam + gk) * 4u : OOB);
+      } else {
+        const int gk = k0 + tid / R4 + (256 / R4) * it, gm = m0 + 4 * (tid % R4);
+        ar[it] = bl4(ra, (gm < g.M && gk < g.K) ? (unsigned)(gk * (int)g.sak + gm) * 4u : OOB);
+      }
+      if (BK) {
+        const int gn = n0 + (tid >> 4) + 16 * it, gk = k0 + 4 * (tid & 15);
+        br[it] = bl4(rb, (gn < g.N && gk < g.K) ? (unsigned)(gn * (int)g.sbn + gk) * 4u : OOB);
+      } else {
+        const int gk = k0 + tid / R4 + (256 / R4) * it, gn = n0 + 4 * (tid % R4);
+        br[it] = bl4(rb, (gn < g.N && gk < g.K) ? (unsigned)(gk * (int)g.sbk + gn) * 4u : OOB);
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      if (AK) *reinterpret_cast<f32x4 *>(As + buf * ASZ + ((tid >> 4) + 16 * it) * LDK + 4 * (tid & 15)) = ar[it];
+      else *reinterpret_cast<f32x4 *>(As + buf * ASZ + (tid / R4 + (256 / R4) * it) * LDR + 4 * (tid % R4)) = ar[it];
+      if (BK) *reinterpret_cast<f32x4 *>(Bs + buf * BSZ + ((tid >> 4) + 16 * it) * LDK + 4 * (tid & 15)) = br[it];
+      else *reinterpret_cast<f32x4 *>(Bs + buf * BSZ + (tid / R4 + (256 / R4) * it) * LDR + 4 * (tid % R4)) = br[it];
+    }
+  };
+  f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nc = (g.K + KC - 1) / KC;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    if (c + 1 < nc) gload((c + 1) * KC);
+    const float *A = As + (c & 1) * ASZ, *B = Bs + (c & 1) * BSZ;
+    const int kkmax = min(4, (g.K - c * KC + 15) >> 4);
+    for (int kk = 0; kk < kkmax; ++kk) {
+      float a[WT][4], b[WT][4];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        if (AK) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(A + (wm + 16 * i + (lane & 15)) * LDK + 16 * kk + 4 * (lane >> 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[i][e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[i][e] = A[(16 * kk + 4 * (lane >> 4) + e) * LDR + wm + 16 * i + (lane & 15)];
+        }
+        if (BK) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(B + (wn + 16 * i + (lane & 15)) * LDK + 16 * kk + 4 * (lane >> 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[i][e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[i][e] = B[(16 * kk + 4 * (lane >> 4) + e) * LDR + wn + 16 * i + (lane & 15)];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+          for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (c + 1 < nc) sstore((c + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int n = n0 + wn + 16 * j + (lane & 15);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+        float *cp = g.C + (size_t)m * g.ldc + n;
+        *cp = g.accumulate ? (*cp + v) : v;
+      }
+    }
+}
+
+template <int BT, bool AK, bool BK>
+void launch_panel(const mmt_gemm_args &g, hipStream_t st) {
+  constexpr int KC = 64, LDK = KC + 4, LDR = BT + 4;
+  constexpr size_t lds = 2 * ((AK ? BT * LDK : KC * LDR) + (BK ? BT * LDK : KC * LDR)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)mmt_gemm_panel_kernel<BT, AK, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((mmt_gemm_panel_kernel<BT, AK, BK>), dim3((g.N + BT - 1) / BT, (g.M + BT - 1) / BT), dim3(256), lds, st, g);
+}
 
 // ------------------------------------------------------------------------------------------ GEMM
 constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;   // LDS row stride 20 floats (16-B aligned rows)
@@ -106,24 +232,34 @@ __global__ __launch_bounds__(256) void mmt_gemm_kernel(mmt_gemm_args g) {
     }
 }
 
-// out[n] (+)= sum_m a[m][n] * (b ? b[m][n] : 1) [only where mask[m][n] > 0]; deterministic order
-__global__ __launch_bounds__(256) void mmt_colsum_kernel(const float *__restrict__ a, const float *__restrict__ b,
-                                                         const float *__restrict__ mask, int M, int N, long lda,
-                                                         long ldb, long ldm, float *__restrict__ out, int accumulate) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+// out[n] (+)= sum_m a[m][n] * (b ? b[m][n] : 1) [only where mask[m][n] > 0]; deterministic order.
+// 16 columns x 64 row-lanes per workgroup: N/16 workgroups, M/64 independent loads per thread.
+__global__ __launch_bounds__(1024) void mmt_colsum_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          const float *__restrict__ mask, int M, int N, long lda,
+                                                          long ldb, long ldm, float *__restrict__ out, int accumulate) {
+  __shared__ float part[64][17];
+  __shared__ float part2[4][16];
+  const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, rl = threadIdx.x >> 4;
   float s = 0.f;
-  if (c < N)
-    for (int m = rl; m < M; m += 4) {
+  if (c < N) {
+#pragma unroll 4
+    for (int m = rl; m < M; m += 64) {
       float v = a[(size_t)m * lda + c];
       if (b) v *= b[(size_t)m * ldb + c];
       if (mask && !(mask[(size_t)m * ldm + c] > 0.f)) v = 0.f;
       s += v;
     }
-  part[rl][threadIdx.x & 63] = s;
+  }
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl < 4) {           // 64 partials per column: 4 lanes x 16 in order, then the 4 lane sums in order
+    float t = 0.f;
+    for (int r = 0; r < 16; ++r) t += part[rl * 16 + r][cl];
+    part2[rl][cl] = t;
+  }
   __syncthreads();
   if (rl == 0 && c < N) {
-    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    const float t = (part2[0][cl] + part2[1][cl]) + (part2[2][cl] + part2[3][cl]);
     out[c] = accumulate ? out[c] + t : t;
   }
 }
@@ -194,98 +330,149 @@ __global__ __launch_bounds__(256) void mmt_ln_bwd_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------ attention
-// One thread per (batch, head, query).  Keys 0..nk-1 with nk = causal ? min(i + 1 + causal_offset, Lk) : Lk;
-// key j masked when pad[b*Lk + j].  All operands addressed by (batch stride, row stride) in floats.
-__global__ void mmt_attn_fwd_kernel(mmt_attn_args a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.B * a.H * a.Lq) return;
-  const int i = idx % a.Lq, h = (idx / a.Lq) % a.H, b = idx / (a.Lq * a.H);
-  const int dh = a.dh;
-  const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * dh;
-  const float *K = a.k + (size_t)b * a.k_bs + h * dh, *V = a.v + (size_t)b * a.v_bs + h * dh;
-  const int nk = a.causal ? min(i + 1 + a.causal_offset, a.Lk) : a.Lk;
-  float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
-  float qv[64], o[64];
-  for (int c = 0; c < dh; ++c) {
-    qv[c] = q[c];
-    o[c] = 0.f;
-  }
-  float mx = -INFINITY;
-  for (int j = 0; j < nk; ++j) {
-    float s = -INFINITY;
-    if (!(a.pad && a.pad[(size_t)b * a.Lk + j])) {
+// 16 lanes per (batch, head, query).  Keys 0..nk-1 with nk = causal ? min(i + 1 + causal_offset, Lk) : Lk (<= 32);
+// key j masked when pad[b*Lk + j].  All operands addressed by (batch stride, row stride) in floats; head slices are
+// 16-byte aligned (dh % 16 == 0, strides % 4 == 0: checked on the host).  Lane j scores keys j and j+16 (row
+// reductions over the DPP row), then owns dh/16 output dims for P.V.
+template <int DH>
+__global__ __launch_bounds__(256) void mmt_attn_fwd_kernel(mmt_attn_args a) {
+  constexpr int NQ = DH / 4, DPL = DH / 16;
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l16 = threadIdx.x & 15;
+  const bool live = grp < a.B * a.H * a.Lq;
+  const int gq = live ? grp : 0;
+  const int i = gq % a.Lq, h = (gq / a.Lq) % a.H, b = gq / (a.Lq * a.H);
+  const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * DH;
+  const float *K = a.k + (size_t)b * a.k_bs + h * DH, *V = a.v + (size_t)b * a.v_bs + h * DH;
+  const int nk = !live ? 0 : a.causal ? min(i + 1 + a.causal_offset, a.Lk) : a.Lk;
+  f32x4 qv[NQ];
+#pragma unroll
+  for (int c = 0; c < NQ; ++c) qv[c] = *reinterpret_cast<const f32x4 *>(q + 4 * c);
+  float sc[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int j = l16 + 16 * hf;
+    if (j < nk && !(a.pad && a.pad[(size_t)b * a.Lk + j])) {
       const float *kj = K + (size_t)j * a.k_rs;
       float acc = 0.f;
-      for (int c = 0; c < dh; ++c) acc = fmaf(qv[c], kj[c], acc);
-      s = acc * a.scale;
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        const f32x4 kv = *reinterpret_cast<const f32x4 *>(kj + 4 * c);
+        acc = fmaf(qv[c][0], kv[0], acc);
+        acc = fmaf(qv[c][1], kv[1], acc);
+        acc = fmaf(qv[c][2], kv[2], acc);
+        acc = fmaf(qv[c][3], kv[3], acc);
+      }
+      sc[hf] = acc * a.scale;
     }
-    P[j] = s;
-    mx = fmaxf(mx, s);
   }
-  float sum = 0.f;
-  for (int j = 0; j < nk; ++j) {
-    const float e = mx > -INFINITY ? expf(P[j] - mx) : 0.f;
-    P[j] = e;
-    sum += e;
+  const float mx = row16_max(fmaxf(sc[0], sc[1]));
+  float p0 = 0.f, p1 = 0.f;
+  if (mx > -INFINITY) {
+    p0 = expf(sc[0] - mx);
+    p1 = expf(sc[1] - mx);
   }
+  const float sum = row16_sum(p0 + p1);
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-  for (int j = 0; j < a.Lk; ++j) {
-    const float p = j < nk ? P[j] * inv : 0.f;
-    P[j] = p;
-    if (p > 0.f) {
-      const float *vj = V + (size_t)j * a.v_rs;
-      for (int c = 0; c < dh; ++c) o[c] = fmaf(p, vj[c], o[c]);
+  p0 *= inv;
+  p1 *= inv;
+  if (live) {
+    float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
+    if (l16 < a.Lk) P[l16] = p0;
+    if (l16 + 16 < a.Lk) P[l16 + 16] = p1;
+  }
+  float o[DPL];
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+  const int nkw = min(nk, 16);
+  for (int j = 0; j < 16; ++j) {
+    const float pj = __shfl(p0, j, 16);
+    if (j < nkw && pj > 0.f) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, V[(size_t)j * a.v_rs + l16 * DPL + e], o[e]);
     }
   }
-  float *out = a.o + (size_t)b * a.o_bs + (size_t)i * a.o_rs + h * dh;
-  for (int c = 0; c < dh; ++c) out[c] = o[c];
+  for (int j = 16; j < 32; ++j) {
+    const float pj = __shfl(p1, j - 16, 16);
+    if (j < nk && pj > 0.f) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, V[(size_t)j * a.v_rs + l16 * DPL + e], o[e]);
+    }
+  }
+  if (live) {
+    float *out = a.o + (size_t)b * a.o_bs + (size_t)i * a.o_rs + h * DH + l16 * DPL;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) out[e] = o[e];
+  }
 }
 
-// One thread per (batch, head): dq (=) , dk += , dv +=  from dO and the stashed probabilities.
-__global__ void mmt_attn_bwd_kernel(mmt_attn_args a, const float *__restrict__ dO, long do_bs, long do_rs,
-                                    float *__restrict__ dq, long dq_bs, long dq_rs, float *__restrict__ dk,
-                                    float *__restrict__ dv, long dk_bs, long dk_rs) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.B * a.H) return;
-  const int h = idx % a.H, b = idx / a.H;
-  const int dh = a.dh;
-  const float *K = a.k + (size_t)b * a.k_bs + h * dh, *V = a.v + (size_t)b * a.v_bs + h * dh;
-  float *dK = dk + (size_t)b * dk_bs + h * dh, *dV = dv + (size_t)b * dk_bs + h * dh;
+// 16 lanes per (batch, head), queries in sequence: dq (=), dk +=, dv += from dO and the stashed probabilities.
+// Per query: lanes = keys for dP_j = dO . v_j and the softmax Jacobian, then lanes = dims for the three updates.
+template <int DH>
+__global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, const float *__restrict__ dO, long do_bs, long do_rs,
+                                                           float *__restrict__ dq, long dq_bs, long dq_rs,
+                                                           float *__restrict__ dk, float *__restrict__ dv, long dk_bs,
+                                                           long dk_rs) {
+  constexpr int NQ = DH / 4, DPL = DH / 16;
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l16 = threadIdx.x & 15;
+  const bool live = grp < a.B * a.H;
+  const int gq = live ? grp : 0;
+  const int h = gq % a.H, b = gq / a.H;
+  const float *K = a.k + (size_t)b * a.k_bs + h * DH, *V = a.v + (size_t)b * a.v_bs + h * DH;
+  float *dK = dk + (size_t)b * dk_bs + h * DH + l16 * DPL, *dV = dv + (size_t)b * dk_bs + h * DH + l16 * DPL;
+  const int Lk = live ? a.Lk : 0;
   for (int i = 0; i < a.Lq; ++i) {
     const float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
-    const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * dh;
-    const float *g = dO + (size_t)b * do_bs + (size_t)i * do_rs + h * dh;
-    float *dqi = dq + (size_t)b * dq_bs + (size_t)i * dq_rs + h * dh;
-    float gv[64], qv[64], dqa[64];
-    for (int c = 0; c < dh; ++c) {
-      gv[c] = g[c];
-      qv[c] = q[c];
-      dqa[c] = 0.f;
-    }
-    float dP[32];
-    float dot = 0.f;
-    for (int j = 0; j < a.Lk; ++j) {
-      float t = 0.f;
-      if (P[j] > 0.f) {
+    const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * DH;
+    const float *g = dO + (size_t)b * do_bs + (size_t)i * do_rs + h * DH;
+    f32x4 gv[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) gv[c] = *reinterpret_cast<const f32x4 *>(g + 4 * c);
+    float p[2] = {0.f, 0.f}, dP[2] = {0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int j = l16 + 16 * hf;
+      if (j < Lk) p[hf] = P[j];
+      if (p[hf] > 0.f) {
         const float *vj = V + (size_t)j * a.v_rs;
-        for (int c = 0; c < dh; ++c) t = fmaf(gv[c], vj[c], t);
-      }
-      dP[j] = t;
-      dot = fmaf(P[j], t, dot);
-    }
-    for (int j = 0; j < a.Lk; ++j) {
-      const float p = P[j];
-      if (!(p > 0.f)) continue;
-      const float ds = p * (dP[j] - dot) * a.scale;
-      const float *kj = K + (size_t)j * a.k_rs;
-      float *dkj = dK + (size_t)j * dk_rs, *dvj = dV + (size_t)j * dk_rs;
-      for (int c = 0; c < dh; ++c) {
-        dqa[c] = fmaf(ds, kj[c], dqa[c]);
-        dkj[c] = fmaf(ds, qv[c], dkj[c]);
-        dvj[c] = fmaf(p, gv[c], dvj[c]);
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) {
+          const f32x4 vv = *reinterpret_cast<const f32x4 *>(vj + 4 * c);
+          t = fmaf(gv[c][0], vv[0], t);
+          t = fmaf(gv[c][1], vv[1], t);
+          t = fmaf(gv[c][2], vv[2], t);
+          t = fmaf(gv[c][3], vv[3], t);
+        }
+        dP[hf] = t;
       }
     }
-    for (int c = 0; c < dh; ++c) dqi[c] = dqa[c];
+    const float dot = row16_sum(fmaf(p[0], dP[0], p[1] * dP[1]));
+    const float ds0 = p[0] * (dP[0] - dot) * a.scale, ds1 = p[1] * (dP[1] - dot) * a.scale;
+    float qd[DPL], gd[DPL], dqa[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+      qd[e] = q[l16 * DPL + e];
+      gd[e] = g[l16 * DPL + e];
+      dqa[e] = 0.f;
+    }
+    for (int j = 0; j < 32; ++j) {
+      const float pj = __shfl(j < 16 ? p[0] : p[1], j & 15, 16), dsj = __shfl(j < 16 ? ds0 : ds1, j & 15, 16);
+      if (j < Lk && pj > 0.f) {
+        const float *kj = K + (size_t)j * a.k_rs + l16 * DPL;
+        float *dkj = dK + (size_t)j * dk_rs, *dvj = dV + (size_t)j * dk_rs;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+          dqa[e] = fmaf(dsj, kj[e], dqa[e]);
+          dkj[e] = fmaf(dsj, qd[e], dkj[e]);
+          dvj[e] = fmaf(pj, gd[e], dvj[e]);
+        }
+      }
+    }
+    if (live) {
+      float *dqi = dq + (size_t)b * dq_bs + (size_t)i * dq_rs + h * DH + l16 * DPL;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) dqi[e] = dqa[e];
+    }
   }
 }
 
@@ -364,6 +551,20 @@ static int launch_ok(const char *what) {
 extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   if (!g || !g->A || !g->B || !g->C) return mmt_set_error(MMT_EINVAL, "mmt_gemm: null pointer");
   if (g->M <= 0 || g->N <= 0 || g->K <= 0) return mmt_set_error(MMT_EINVAL, "mmt_gemm: empty problem %dx%dx%d", g->M, g->N, g->K);
+  // panel kernel: 16-byte aligned operands whose unit stride is K or the row index, all offsets within 2^31 bytes
+  const bool ak = g->sak == 1 && g->sam % 4 == 0, ar = g->sam == 1 && g->sak % 4 == 0 && g->M % 4 == 0;
+  const bool bk = g->sbk == 1 && g->sbn % 4 == 0, br = g->sbn == 1 && g->sbk % 4 == 0 && g->N % 4 == 0;
+  const bool aligned = (((uintptr_t)g->A | (uintptr_t)g->B) & 15) == 0 && g->K % 4 == 0;
+  const double amax = (double)g->M * (double)(ak ? g->sam : 1) + (double)g->K * (double)(ak ? 1 : g->sak);
+  const double bmax = (double)g->N * (double)(bk ? g->sbn : 1) + (double)g->K * (double)(bk ? 1 : g->sbk);
+  if (aligned && (ak || ar) && (bk || br) && !(ar && !ak && bk) && amax < 5e8 && bmax < 5e8) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = ((g->M + 63) / 64) * ((g->N + 63) / 64) >= 128;
+    if (ak && bk) big ? launch_panel<64, true, true>(*g, st) : launch_panel<32, true, true>(*g, st);
+    else if (ak) big ? launch_panel<64, true, false>(*g, st) : launch_panel<32, true, false>(*g, st);
+    else big ? launch_panel<64, false, false>(*g, st) : launch_panel<32, false, false>(*g, st);
+    return launch_ok("mmt_gemm");
+  }
   dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM);
   hipLaunchKernelGGL(mmt_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *g);
   return launch_ok("mmt_gemm");
@@ -372,7 +573,7 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
 extern "C" int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,
                           float *out, int accumulate, void *stream) {
   if (!a || !out || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_colsum: bad arguments");
-  hipLaunchKernelGGL(mmt_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, b, mask, M, N, lda, ldb,
+  hipLaunchKernelGGL(mmt_colsum_kernel, dim3((N + 15) / 16), dim3(1024), 0, (hipStream_t)stream, a, b, mask, M, N, lda, ldb,
                      ldm, out, accumulate);
   return launch_ok("mmt_colsum");
 }
@@ -395,16 +596,22 @@ extern "C" int mmt_layernorm_bwd(const float *dy, const float *xhat, const float
 
 static int check_attn(const mmt_attn_args *a, const char *who) {
   if (!a || !a->q || !a->k || !a->v || !a->probs) return mmt_set_error(MMT_EINVAL, "%s: null pointer", who);
-  if (a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->Lk > 32 || a->dh <= 0 || a->dh > 64)
-    return mmt_set_error(MMT_EINVAL, "%s: need B,H,Lq > 0, 1 <= Lk <= 32, 1 <= dh <= 64", who);
+  if (a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->Lk > 32 || (a->dh != 16 && a->dh != 32 && a->dh != 64))
+    return mmt_set_error(MMT_EINVAL, "%s: need B,H,Lq > 0, 1 <= Lk <= 32, head dim 16, 32 or 64", who);
+  if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15 || (a->q_bs | a->q_rs | a->k_bs | a->k_rs | a->v_bs | a->v_rs) & 3)
+    return mmt_set_error(MMT_EINVAL, "%s: q/k/v head slices must be 16-byte aligned (strides multiples of 4 floats)", who);
   return MMT_OK;
 }
 
 extern "C" int mmt_attention_fwd(const mmt_attn_args *a, void *stream) {
   if (int rc = check_attn(a, "mmt_attention_fwd")) return rc;
   if (!a->o) return mmt_set_error(MMT_EINVAL, "mmt_attention_fwd: null output");
-  const int total = a->B * a->H * a->Lq;
-  hipLaunchKernelGGL(mmt_attn_fwd_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
+  const int total = a->B * a->H * a->Lq;                 // groups of 16 lanes
+  const dim3 grid((total + 15) / 16), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->dh == 16) hipLaunchKernelGGL(mmt_attn_fwd_kernel<16>, grid, blk, 0, st, *a);
+  else if (a->dh == 32) hipLaunchKernelGGL(mmt_attn_fwd_kernel<32>, grid, blk, 0, st, *a);
+  else hipLaunchKernelGGL(mmt_attn_fwd_kernel<64>, grid, blk, 0, st, *a);
   return launch_ok("mmt_attention_fwd");
 }
 
@@ -412,9 +619,14 @@ extern "C" int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long 
                                  long dq_rs, float *dk, float *dv, long dk_bs, long dk_rs, void *stream) {
   if (int rc = check_attn(a, "mmt_attention_bwd")) return rc;
   if (!d_o || !dq || !dk || !dv) return mmt_set_error(MMT_EINVAL, "mmt_attention_bwd: null gradient pointer");
-  const int total = a->B * a->H;
-  hipLaunchKernelGGL(mmt_attn_bwd_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a, d_o, do_bs, do_rs, dq,
-                     dq_bs, dq_rs, dk, dv, dk_bs, dk_rs);
+  if (((uintptr_t)d_o & 15) || ((do_bs | do_rs) & 3))
+    return mmt_set_error(MMT_EINVAL, "mmt_attention_bwd: d_o head slices must be 16-byte aligned");
+  const int total = a->B * a->H;                         // groups of 16 lanes
+  const dim3 grid((total + 15) / 16), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define BWD(DHV) hipLaunchKernelGGL(mmt_attn_bwd_kernel<DHV>, grid, blk, 0, st, *a, d_o, do_bs, do_rs, dq, dq_bs, dq_rs, dk, dv, dk_bs, dk_rs)
+  if (a->dh == 16) BWD(16); else if (a->dh == 32) BWD(32); else BWD(64);
+#undef BWD
   return launch_ok("mmt_attention_bwd");
 }
 
