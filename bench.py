@@ -264,6 +264,18 @@ def main():
         kt = time_kernels(model, reg, (x, x_st, lanes, maps), ph, iters=min(50, max(5, args.steps)))
         dec_flops = (MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * (1 if args.mode != "lane_cnn" or model.lane_dedup else 3)
         achieved = dec_flops / (kt["decoder_ms"] * 1e-3) / 1e12
+        n_dec_par = sum(p.numel() for k, m in reg.model_dict.items() if "decoder" in k or "fusion" in k
+                        for p in m.parameters())
+        dec_bytes = 4.0 * (n_dec_par + B * (args.history + 1) * hp["transformer"]["in_dim"] + B * ph * 2)
+        cluster = args.decoder != "persistent" and B <= 512 and args.history + 1 <= 16 and ph <= 16
+        dec_kernel = ("mmt_dec_phase_kernel x%d + mmt_dec_ckv_kernel (cluster decoder)" % (3 * 6 * ph + 1)) if cluster \
+            else "mmt_decoder_kernel (persistent decoder)"
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r01", "traffic_b128_basic_v2.json")
+        if cluster and args.mode == "basic" and B == 128 and ph == 12 and args.history == 8 and os.path.exists(tf):
+            # HBM-side bytes per decode from separate rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+            traffic = json.load(open(tf))["decoder_bytes_per_predict"]
+            traffic_src = "profiles/r01/traffic_b128_basic_v2.json (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)"
         line = {
             "metric": "predicted agents/sec (12-step, batch 128)",
             "value": value, "unit": "agents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,9 +286,13 @@ def main():
                                    f"{args.history}-step history, {ph}-step horizon",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-split x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "mmt_decoder_kernel", "avg_launch_ms": kt["decoder_ms"],
-                         "algorithmic_flop_per_launch": dec_flops},
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "kernel": dec_kernel, "launch_unit": "one 12-step decode (all of its launches)",
+                         "avg_launch_ms": kt["decoder_ms"], "algorithmic_flop_per_launch": dec_flops,
+                         # the HBM view of the same launches (north_star asks for it): weights once + memory + outputs
+                         "algorithmic_bytes_per_launch": dec_bytes,
+                         "achieved_gbs_vs_hbm": dec_bytes / (kt["decoder_ms"] * 1e-3) / 1e9, "hbm_peak_gbs": 8000.0},
             "kernels_ms": kt,
         }
         if args.sweep and not distributed:
