@@ -241,6 +241,15 @@ int mmt_history_prepare(const float *x_st, int rows, int n_in, float *x0, uint8_
 /* state[0] += 1 (step count), state[1] *= gamma: ExponentialLR stepped once per batch (train.py:226-227,253-256) */
 int mmt_lr_step(float *state_dev, float gamma, void *stream);
 
+/* ---- stand-alone Mlp / teacher-forced pieces -----------------------------------------------------------------
+ * softmax over the middle axis of a contiguous (outer, n, inner) tensor: nn.Softmax() of Mlp(mode='classification')
+ * (MLP.py:18-21; dim=None resolves to dim 0 of the 3-D input it receives: outer=1, n=B, inner=ph*out) */
+int mmt_softmax_axis(const float *x, long outer, int n, long inner, float *y, void *stream);
+/* torch.cumsum over the middle axis: mlp(h).cumsum(dim=-2) of non_at_dec (mgcvae.py:352,370) */
+int mmt_cumsum_axis(const float *x, long outer, int n, long inner, float *y, void *stream);
+/* y += x (gradient of that cumsum walked backwards in time) */
+int mmt_add_inplace(float *y, const float *x, long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,9 @@ SIGNATURES = {
                                   C.c_void_p]),
     "mmt_history_prepare": (C.c_int, [fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_lr_step": (C.c_int, [fptr, C.c_float, C.c_void_p]),
+    "mmt_softmax_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
+    "mmt_cumsum_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
+    "mmt_add_inplace": (C.c_int, [fptr, fptr, C.c_long, C.c_void_p]),
     "mmt_finalize": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_void_p]),
 }
 

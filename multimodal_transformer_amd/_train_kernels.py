@@ -226,3 +226,36 @@ def lr_step(state, gamma):
     _contig2(state, "state", (2,))
     lib = _lib.load()
     _lib.check(lib.mmt_lr_step(_p(state), float(gamma), _stream()), "mmt_lr_step")
+
+
+def softmax_axis(x, y, axis):
+    """y = softmax(x) over ``axis`` of a contiguous tensor (nn.Softmax)."""
+    _contig2(x, "x", x.shape), _contig2(y, "y", x.shape)
+    outer = 1
+    for s in x.shape[:axis]:
+        outer *= s
+    inner = 1
+    for s in x.shape[axis + 1:]:
+        inner *= s
+    lib = _lib.load()
+    _lib.check(lib.mmt_softmax_axis(_p(x), outer, x.shape[axis], inner, _p(y), _stream()), "mmt_softmax_axis")
+
+
+def cumsum_axis(x, y, axis):
+    """y = cumsum(x) over ``axis`` of a contiguous tensor."""
+    _contig2(x, "x", x.shape), _contig2(y, "y", x.shape)
+    outer = 1
+    for s in x.shape[:axis]:
+        outer *= s
+    inner = 1
+    for s in x.shape[axis + 1:]:
+        inner *= s
+    lib = _lib.load()
+    _lib.check(lib.mmt_cumsum_axis(_p(x), outer, x.shape[axis], inner, _p(y), _stream()), "mmt_cumsum_axis")
+
+
+def add_inplace(y, x):
+    """y += x (contiguous, same shape)."""
+    _contig2(y, "y", y.shape), _contig2(x, "x", y.shape)
+    lib = _lib.load()
+    _lib.check(lib.mmt_add_inplace(_p(y), _p(x), y.numel(), _stream()), "mmt_add_inplace")

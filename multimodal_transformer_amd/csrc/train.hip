@@ -533,6 +533,39 @@ __global__ void mmt_history_prepare_kernel(const float *__restrict__ x, int rows
   if (idx % n == 1) pad[idx / n] = (v != v) ? 1 : 0;
 }
 
+// y[o][j][i] = softmax_j x[o][j][i]  (nn.Softmax over one axis of a contiguous tensor; the reference's
+// Mlp(mode='classification') applies it with dim=None, i.e. over dim 0 of its 3-D input, MLP.py:18-21)
+__global__ void mmt_softmax_axis_kernel(const float *__restrict__ x, long outer, int n, long inner, float *__restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= outer * inner) return;
+  const long o = idx / inner, i = idx - o * inner;
+  const float *xp = x + o * n * inner + i;
+  float *yp = y + o * n * inner + i;
+  float mx = -INFINITY;
+  for (int j = 0; j < n; ++j) mx = fmaxf(mx, xp[j * inner]);
+  float sum = 0.f;
+  for (int j = 0; j < n; ++j) sum += expf(xp[j * inner] - mx);
+  const float inv = 1.0f / sum;
+  for (int j = 0; j < n; ++j) yp[j * inner] = expf(xp[j * inner] - mx) * inv;
+}
+
+// y[o][t][i] = sum_{u <= t} x[o][u][i]   (torch.cumsum over one axis; mgcvae.py:352,370)
+__global__ void mmt_cumsum_axis_kernel(const float *__restrict__ x, long outer, int n, long inner, float *__restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= outer * inner) return;
+  const long o = idx / inner, i = idx - o * inner;
+  float acc = 0.f;
+  for (int j = 0; j < n; ++j) {
+    acc += x[(o * n + j) * inner + i];
+    y[(o * n + j) * inner + i] = acc;
+  }
+}
+
+__global__ void mmt_add_inplace_kernel(float *__restrict__ y, const float *__restrict__ x, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+
 __global__ void mmt_lr_step_kernel(float *state, float gamma) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     state[0] += 1.0f;
@@ -656,4 +689,26 @@ extern "C" int mmt_lr_step(float *state_dev, float gamma, void *stream) {
   if (!state_dev) return mmt_set_error(MMT_EINVAL, "mmt_lr_step: null state");
   hipLaunchKernelGGL(mmt_lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, gamma);
   return launch_ok("mmt_lr_step");
+}
+
+extern "C" int mmt_softmax_axis(const float *x, long outer, int n, long inner, float *y, void *stream) {
+  if (!x || !y || outer <= 0 || n <= 0 || inner <= 0) return mmt_set_error(MMT_EINVAL, "mmt_softmax_axis: bad arguments");
+  const long total = outer * inner;
+  hipLaunchKernelGGL(mmt_softmax_axis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, outer, n,
+                     inner, y);
+  return launch_ok("mmt_softmax_axis");
+}
+
+extern "C" int mmt_cumsum_axis(const float *x, long outer, int n, long inner, float *y, void *stream) {
+  if (!x || !y || outer <= 0 || n <= 0 || inner <= 0) return mmt_set_error(MMT_EINVAL, "mmt_cumsum_axis: bad arguments");
+  const long total = outer * inner;
+  hipLaunchKernelGGL(mmt_cumsum_axis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, outer, n,
+                     inner, y);
+  return launch_ok("mmt_cumsum_axis");
+}
+
+extern "C" int mmt_add_inplace(float *y, const float *x, long n, void *stream) {
+  if (!x || !y || n <= 0) return mmt_set_error(MMT_EINVAL, "mmt_add_inplace: bad arguments");
+  hipLaunchKernelGGL(mmt_add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, x, n);
+  return launch_ok("mmt_add_inplace");
 }

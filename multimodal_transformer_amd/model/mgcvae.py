@@ -140,6 +140,32 @@ class MultimodalGenerativeCVAE(object):
                                       map_feat=map_feature)
         return pred, []
 
+    def non_at_dec(self, memory, memory_mask, memory_key_padding_mask, labels_st, n_s_t0, lane_feature, map_feature,
+                   prediction_horizon):
+        """mgcvae.py:310-373: ONE teacher-forced decoder pass on cat[0, labels_st[:, :-1]], then
+        ``mlp(h).cumsum(dim=-2)``.  Basic configuration only: in the reference the map branch concatenates a
+        (B,ph,32) with a (B,1,32) tensor (:365-367, fails for ph > 1) and the lane branch crashes downstream on its
+        empty ``class_input`` (:502), so neither has defined behaviour to reproduce."""
+        from .. import _train_kernels as K
+        hp = self.hyperparams
+        if hp["lane_cnn_encoding"] or hp["map_cnn_encoding"] or hp["map_vit_encoding"]:
+            raise MmtError("non_at_dec is only defined for the Basic configuration (the reference's map / lane "
+                           "branches of non_at_dec do not run, mgcvae.py:365-367 and :502)")
+        dec, head = self._m("decoder/transformer_decoder"), self._m("decoder/MLP")
+        B = memory.shape[0]
+        tgt = torch.cat([torch.zeros(B, 1, self.pred_state_length, device=memory.device), labels_st[:, :-1, :]],
+                        dim=-2).contiguous()
+        h = dec(tgt, memory, None, memory_mask, memory_key_padding_mask)
+        delta = head(h).contiguous()
+        hist = torch.empty_like(delta)
+        K.cumsum_axis(delta, hist, 1)
+        return hist, None
+
+    def classification_lane(self, encoded_lane):
+        """mgcvae.py:552-557: Lane/MLP_Softmax on the concatenated per-lane decoder states (result unused by the
+        reference's losses, :610-611 are commented out)."""
+        return self._m("Lane/MLP_Softmax")(encoded_lane)
+
     def at_dec_lane(self, dec, head, memory, pad, start, lane_feature, ph):
         """Lane branch (mgcvae.py:395-424).  The reference overwrites ``lane_feature`` inside its lane loop
         (:404), so lanes 1 and 2 are decoded with lane 0's feature and -- dropout off -- are bit-identical to
@@ -204,12 +230,15 @@ class MultimodalGenerativeCVAE(object):
         (training.py) and fills ``.grad`` of every parameter, so the reference's loop (train.py:244-253) works
         unchanged; ``training.Trainer`` is the fused, graph-replayed equivalent of that whole loop body.
         Map / lane configurations: forward value only (their context encoders have no backward kernels yet)."""
-        if not self.hyperparams["autoregressive"]:
-            raise MmtError("teacher-forced training (non_at_dec) is not implemented; pass autoregressive=True")
         hp = self.hyperparams
-        if not (hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"]):
+        basic = not (hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"])
+        if not hp["autoregressive"] and not basic:
+            raise MmtError("teacher-forced training (non_at_dec) is only defined for the Basic configuration "
+                           "(mgcvae.py:365-367 and :502 do not run in the reference)")
+        if basic:
             from ..training import train_loss_with_graph
-            loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon)
+            loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon,
+                                         teacher_forced=not hp["autoregressive"])
         else:
             loss = self._loss(inputs, inputs_st, inputs_lane, labels, labels_st, map, prediction_horizon, False,
                               ModeKeys.EVAL)

@@ -185,8 +185,46 @@ class Mlp(_PackedMixin, nn.Module):
         self.mode = mode
 
     def forward(self, x):
-        raise MmtError("Mlp runs fused inside the decoder kernel (head / fusion); call "
-                       "Trajectory_Decoder.packed(head=..., map_fusion=..., mem_fusion=...) instead")
+        """Stand-alone call (MLP.py:28-30) on the whole-batch kernels: per hidden layer one GEMM (+bias) and one
+        LayerNorm+ReLU launch, then the output GEMM; classification mode ends in ``nn.Softmax()`` with dim=None,
+        which torch resolves to dim 0 for 0-, 1- and 3-D inputs and dim 1 otherwise (so the (B, ph, 96) tensor
+        the reference feeds it is normalised over the BATCH).  Inside the decoders the same
+        modules run fused (``Trajectory_Decoder.packed(head=..., map_fusion=..., mem_fusion=...)``)."""
+        from .. import _train_kernels as K
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise MmtError("Mlp.forward needs a device tensor (no CPU fallback)")
+        if x.dtype != torch.float32:
+            raise MmtError(f"Mlp.forward: dtype {x.dtype}, expected torch.float32")
+        shape = x.shape
+        z = x.contiguous().view(-1, shape[-1])
+        rows = z.shape[0]
+        if rows == 0:
+            raise MmtError("Mlp.forward: empty input")
+        i = 0
+        while hasattr(self.layer_seq, f"lmlp_{i}"):
+            lin, ln = getattr(self.layer_seq, f"lmlp_{i}")[0], getattr(self.layer_seq, f"lmlp_{i}")[1]
+            if z.shape[1] != lin.weight.shape[1]:
+                raise MmtError(f"Mlp.forward: {z.shape[1]} input features, layer expects {lin.weight.shape[1]}")
+            u = torch.empty(rows, lin.weight.shape[0], dtype=torch.float32, device=x.device)
+            K.gemm(z, lin.weight.t(), u, bias=lin.bias)
+            y = torch.empty_like(u)
+            K.layernorm_fwd(u, None, ln.weight, ln.bias, y, torch.empty_like(u),
+                            torch.empty(rows, dtype=torch.float32, device=x.device), relu=True)
+            z = y
+            i += 1
+        out = self.layer_seq.out_mlp
+        lin = out if isinstance(out, nn.Linear) else out[0]
+        if z.shape[1] != lin.weight.shape[1]:
+            raise MmtError(f"Mlp.forward: {z.shape[1]} input features, output layer expects {lin.weight.shape[1]}")
+        y = torch.empty(rows, lin.weight.shape[0], dtype=torch.float32, device=x.device)
+        K.gemm(z, lin.weight.t(), y, bias=lin.bias)
+        y = y.view(*shape[:-1], lin.weight.shape[0])
+        if not isinstance(out, nn.Linear):
+            axis = 0 if y.dim() in (0, 1, 3) else 1           # torch.nn.functional._get_softmax_dim
+            sm = torch.empty_like(y)
+            K.softmax_axis(y, sm, axis)
+            y = sm
+        return y
 
 
 class CNNMapEncoder(_PackedMixin, nn.Module):

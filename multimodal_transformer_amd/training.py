@@ -39,13 +39,14 @@ class _Stash:
 class TrainEngine:
     """Forward-with-stash + backward for one (B, T, ph) shape of the Basic configuration."""
 
-    def __init__(self, model, B, T, ph, device=None):
+    def __init__(self, model, B, T, ph, device=None, teacher_forced=None):
         hp = model.hyperparams
+        # non_at_dec (mgcvae.py:310-373): tokens come from the labels, positions are the running sum of the head
+        # outputs and are NOT fed back, so no gradient flows through the tokens
+        self.teacher_forced = (not hp.get("autoregressive", True)) if teacher_forced is None else bool(teacher_forced)
         if hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"]:
             raise MmtError("the HIP training step covers the Basic configuration (BASELINE config 2); "
                            "map / lane context encoders have no backward kernels yet")
-        if not hp.get("autoregressive", True):
-            raise MmtError("teacher-forced training (non_at_dec) is not implemented; pass autoregressive=True")
         self.enc = model._m("node_history_encoder")
         self.dec = model._m("decoder/transformer_decoder")
         self.head = model._m("decoder/MLP")
@@ -144,6 +145,7 @@ class TrainEngine:
         # decoder activations, step-major
         L = self.Ld
         S.pos = b(ph + 1, B, self.n_pos)
+        S.tok = b(ph, B, self.n_pos) if self.teacher_forced else S.pos[:ph]      # decoder input tokens, step-major
         S.x = [b(ph, B, d) for _ in range(L + 1)]
         S.qkv = [b(ph, B, 3 * d) for _ in range(L)]
         S.p1 = [b(ph, B * H * ph) for _ in range(L)]
@@ -205,9 +207,15 @@ class TrainEngine:
         for l, lay in enumerate(layers):
             ca = lay.multihead_attn
             K.gemm(memory, _t(ca.in_proj_weight[d:]), S.mkv[l], bias=ca.in_proj_bias[d:])
-        S.pos[0].copy_(self.x_st[:, -1, 0:self.n_pos])          # start token = standardised current position
+        if self.teacher_forced:     # tgt = cat[0, labels_st[:, :-1]], positions start from 0 (mgcvae.py:334-335,370)
+            S.pos[0].zero_()
+            S.tok[0].zero_()
+            if ph > 1:
+                S.tok[1:].copy_(self.y_st[:, :ph - 1].permute(1, 0, 2))
+        else:
+            S.pos[0].copy_(self.x_st[:, -1, 0:self.n_pos])      # start token = standardised current position
         for s in range(ph):
-            K.gemm(S.pos[s], _t(dec.input_fc.weight), S.x[0][s], bias=dec.input_fc.bias,
+            K.gemm(S.tok[s], _t(dec.input_fc.weight), S.x[0][s], bias=dec.input_fc.bias,
                    addend=S.pe_dec[s:s + 1].expand(B, d))
             for l, lay in enumerate(layers):
                 sa, ca = lay.self_attn, lay.multihead_attn
@@ -299,12 +307,14 @@ class TrainEngine:
                                 gc[0:s + 1, :, d:2 * d].permute(1, 0, 2), gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), H,
                                 self.scale)
                 K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s])
-            if s > 0:      # G[s] = dL/dpos[s] (already there) + residual path + embedding path
+            if s > 0 and self.teacher_forced:      # G[s] = dL/dpos[s] + residual (cumsum) path; tokens are constants
+                K.add_inplace(S.G[s], S.G[s + 1])
+            elif s > 0:    # G[s] = dL/dpos[s] (already there) + residual path + embedding path
                 K.gemm(S.gx[0][s], dec.input_fc.weight, S.G[s], addend=S.G[s + 1], accumulate=True)
         # ---- deferred decoder weight gradients: one GEMM per Linear over all ph*B rows
         R = ph * B
         f2 = lambda t: t.view(R, t.shape[-1])
-        self._wgrad(f2(S.gx[0]), f2(S.pos[:ph]), dec.input_fc.weight, dec.input_fc.bias)
+        self._wgrad(f2(S.gx[0]), f2(S.tok), dec.input_fc.weight, dec.input_fc.bias)
         memory = S.eh[self.Le]
         for l, lay in enumerate(layers):
             sa, ca = lay.self_attn, lay.multihead_attn
@@ -375,14 +385,14 @@ class _TrainLossFn(torch.autograd.Function):
         return (None,) + tuple(eng.g(p) for _, p in eng.named_params)
 
 
-def train_loss_with_graph(model, x_st, y_st, ph):
+def train_loss_with_graph(model, x_st, y_st, ph, teacher_forced=False):
     """``MultimodalGenerativeCVAE.train_loss`` body for the Basic configuration: a scalar that carries autograd."""
     B, T, _ = x_st.shape
-    key = (B, T, ph)
+    key = (B, T, ph, bool(teacher_forced))
     cache = model.__dict__.setdefault("_train_engines", {})
     eng = cache.get(key)
     if eng is None:
-        eng = cache[key] = TrainEngine(model, B, T, ph)
+        eng = cache[key] = TrainEngine(model, B, T, ph, teacher_forced=teacher_forced)
     eng.set_batch(x_st, y_st)
     return _TrainLossFn.apply(eng, *[p for _, p in eng.named_params])
 

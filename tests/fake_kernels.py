@@ -146,7 +146,19 @@ def lr_step(state, gamma):
     state[1] *= gamma
 
 
-ALL = ("gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
+def softmax_axis(x, y, axis):
+    y.copy_(torch.softmax(x.double(), dim=axis).to(y.dtype))
+
+
+def cumsum_axis(x, y, axis):
+    y.copy_(torch.cumsum(x.double(), dim=axis).to(y.dtype))
+
+
+def add_inplace(y, x):
+    y.add_(x)
+
+
+ALL = ("softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
        "history_prepare", "adamw_table", "adamw_step", "lr_step")
 
 

@@ -209,8 +209,82 @@ def run_mode(mode, tiny):
           "eval_loss", float(out["eval_loss"]), "ADE mean", float(out["ade"].mean()))
 
 
+def run_nonar():
+    """Teacher-forced training (train.py without --autoregressive -> non_at_dec, mgcvae.py:310-373), Basic, tiny config:
+    hist_pred, train_loss, gradients and the parameters after one AdamW step.  Weights / inputs are those of
+    tiny_basic.npz (same recipe, same batch)."""
+    hp = make_hyperparams("basic", history=4, horizon=3, autoregressive=False,
+                          transformer={"nlayers": 2, "nhead": 2, "in_dim": 32, "fdim": 64, "output_size": 32})
+    B, ph = 4, 3
+    model, reg = build_reference(hp, seed=1234)
+    apply_recipe(reg.model_dict, seed=0)
+    batch = make_batch(B, history=hp["maximum_history_length"], horizon=ph, seed=1)
+    x, x_st, y, y_st, lanes, maps = tensors(batch)
+    zero_dropout(reg, hp)
+    for m in reg.model_dict.values():
+        m.train()
+    out, meta = {}, {"mode": "basic", "autoregressive": False, "B": B, "ph": ph, "torch": torch.__version__}
+    with torch.no_grad():
+        (memory, smask, pmask, n0, pos, _, _) = model.obtain_encoded_tensors(mode=None, inputs=x, inputs_st=x_st,
+                                                                            inputs_lane=None, map=None)
+        hist, _ = model.non_at_dec(memory, smask, pmask, y_st, n0, None, None, ph)
+    out["hist_pred"] = hist.numpy()
+    opt = torch.optim.AdamW(
+        [{"params": reg.get_all_but_name_match("map_encoder").parameters()},
+         {"params": reg.get_name_match("map_encoder").parameters(), "lr": 0.0008}], lr=hp["learning_rate"])
+    opt.zero_grad()
+    loss, _ = model.train_loss(inputs=x, inputs_st=x_st, inputs_lane=None, lane_label=None, lane_t_mask=None,
+                               labels=y, labels_st=y_st, map=None, prediction_horizon=ph)
+    loss.backward()
+    out["train_loss"] = np.float32(loss.item())
+    grad_norms = {}
+    for name, mod in reg.model_dict.items():
+        for pn_, p in mod.named_parameters():
+            key = f"{name}.{pn_}"
+            grad_norms[key] = None if p.grad is None else float(p.grad.double().norm())
+            if p.grad is not None:
+                out["grad::" + key] = p.grad.numpy().copy()
+    meta["grad_norms"] = grad_norms
+    nn.utils.clip_grad_value_(reg.parameters(), hp["grad_clip"])
+    opt.step()
+    for name, mod in reg.model_dict.items():
+        for pn_, p in mod.named_parameters():
+            out["post::" + f"{name}.{pn_}"] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "tiny_basic_nonar.npz"), **out)
+    with open(os.path.join(HERE, "tiny_basic_nonar.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("tiny_basic_nonar train_loss", float(out["train_loss"]))
+
+
+def run_mlp():
+    """nn_component.MLP.Mlp stand-alone: regression and classification (nn.Softmax() with dim=None: dim 0 for the 3-D
+    input the reference gives it, dim 1 for a 2-D one)."""
+    from nn_component.MLP import Mlp          # reference
+    import warnings
+    out = {}
+    for tag, mode, nin, nout, layers in (("cls", "classification", 96, 3, 2), ("reg", "regression", 32, 2, 3)):
+        torch.manual_seed(7)
+        m = Mlp(nin, nout, layers, mode)
+        g = torch.Generator().manual_seed(11)
+        x3, x2 = torch.randn(4, 3, nin, generator=g), torch.randn(5, nin, generator=g)
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[f"{tag}::y3"], out[f"{tag}::y2"] = m(x3).numpy(), m(x2).numpy()
+        out[f"{tag}::x3"], out[f"{tag}::x2"] = x3.numpy(), x2.numpy()
+        for k, v in m.state_dict().items():
+            out[f"{tag}::w::{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "mlp_standalone.npz"), **out)
+    print("mlp_standalone", {k: v.shape for k, v in out.items() if "::y" in k})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for tiny in (True, False):
-        for mode in ("basic", "map_cnn", "lane_cnn"):
-            run_mode(mode, tiny)
+    what = sys.argv[1:] or ["modes", "nonar", "mlp"]
+    if "modes" in what:
+        for tiny in (True, False):
+            for mode in ("basic", "map_cnn", "lane_cnn"):
+                run_mode(mode, tiny)
+    if "nonar" in what:
+        run_nonar()
+    if "mlp" in what:
+        run_mlp()

@@ -22,9 +22,9 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _model(hp, dev):
+def _model(hp, dev, autoregressive=True):
     from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
-    hp["autoregressive"] = True
+    hp["autoregressive"] = autoregressive
     reg = ModelRegistrar("/tmp", dev)
     return MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, []), reg
 
@@ -295,3 +295,63 @@ def test_autograd_entry_point_on_device():
     # predictions after the step run through the inference kernels on the updated weights (pack cache invalidated)
     hist, _ = model.predict(t["x"], t["x_st"], None, None, None, ph)
     assert torch.isfinite(hist).all()
+
+
+def test_teacher_forced_step_matches_reference_non_at_dec():
+    """train.py without --autoregressive -> non_at_dec (mgcvae.py:310-373): forward (decoder tgt mode + stand-alone Mlp
+    + cumsum), loss with autograd, gradients and post-AdamW parameters against tests/golden/tiny_basic_nonar.npz."""
+    from multimodal_transformer_amd import training
+    dev = _dev()
+    z0, _ = load_golden("tiny_basic")
+    z, meta = load_golden("tiny_basic_nonar")
+    hp, B, ph = hp_for("basic", True)
+    model, reg = _model(hp, dev, autoregressive=False)
+    set_weights(reg.model_dict, True, z0)
+    batch = batch_for("basic", True)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+    # the model-graph entry point (mgcvae.non_at_dec)
+    memory, _, pad, n0, _, _, _ = model.obtain_encoded_tensors(None, t["x"], t["x_st"], None, None)
+    hist, lane = model.non_at_dec(memory, None, pad, t["y_st"], n0, None, None, ph)
+    assert lane is None and rel_err(hist.cpu().numpy(), z["hist_pred"]) <= TOL
+    # reference-style loop through train_loss (carries autograd)
+    loss, _ = model.train_loss(t["x"], t["x_st"], None, None, None, t["y"], t["y_st"], None, ph)
+    assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
+    loss.backward()
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            if meta["grad_norms"][key] is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, key
+            else:
+                assert rel_err(p.grad.cpu().numpy(), z["grad::" + key]) <= TOL, key
+    # fused trainer on a fresh copy of the weights
+    model2, reg2 = _model(hp, dev, autoregressive=False)
+    set_weights(reg2.model_dict, True, z0)
+    tr = training.Trainer(model2, B, t["x_st"].shape[1], ph, use_graph=True)
+    loss2 = tr.step(t["x_st"], t["y_st"])
+    assert abs(float(loss2) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
+    for name, mod in reg2.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            ok, e = check_post_step(p.detach().cpu().numpy(), z["post::" + key],
+                                    z["grad::" + key] if "grad::" + key in z.files else None, hp["learning_rate"])
+            assert ok, (key, e)
+
+
+def test_standalone_mlp_matches_reference_including_batch_dim_softmax():
+    """nn_component.Mlp called on its own (MLP.py:28-30): regression and classification; the classification
+    Softmax() has dim=None -> dim 0 of the 3-D input (a softmax over the batch), dim 1 of a 2-D one."""
+    from multimodal_transformer_amd.nn_component import Mlp
+    dev = _dev()
+    z = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "mlp_standalone.npz"))
+    for tag, mode, nin, nout, layers in (("cls", "classification", 96, 3, 2), ("reg", "regression", 32, 2, 3)):
+        m = Mlp(nin, nout, layers, mode).to(dev)
+        sd = {k[len(tag) + 5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + "::w::")}
+        m.load_state_dict(sd)
+        for x, y in ((z[f"{tag}::x3"], z[f"{tag}::y3"]), (z[f"{tag}::x2"], z[f"{tag}::y2"])):
+            got = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+            assert got.shape == y.shape
+            assert rel_err(got, y) <= TOL, (tag, x.shape)
+    from multimodal_transformer_amd._lib import MmtError
+    with pytest.raises(MmtError):
+        m(torch.zeros(3, 32))            # CPU tensor: no fallback

@@ -133,3 +133,33 @@ def test_ragged_shape_gradients_match_torch_autograd_of_the_oracle(monkeypatch):
         key, pn = name.rsplit("/", 1)[0] + "/" + name.rsplit("/", 1)[1].split(".", 1)[0], name.rsplit("/", 1)[1].split(".", 1)[1]
         want = leaves[f"{alias[key]}.{pn}"].grad
         assert rel_err(g.numpy(), want.numpy()) <= GRAD_TOL, name
+
+
+def test_teacher_forced_step_matches_reference_non_at_dec(monkeypatch):
+    """train.py without --autoregressive: non_at_dec (mgcvae.py:310-373).  Loss, gradients and the parameters after
+    one AdamW step against the reference's autograd (tests/golden/tiny_basic_nonar.npz)."""
+    from multimodal_transformer_amd import training
+    fake_kernels.install(monkeypatch)
+    z0, _ = load_golden("tiny_basic")
+    z, meta = load_golden("tiny_basic_nonar")
+    hp, B, ph = hp_for("basic", True)
+    hp["autoregressive"] = False
+    model, reg = _model(hp)
+    set_weights(reg.model_dict, True, z0)
+    batch = batch_for("basic", True)
+    x_st, y_st = torch.from_numpy(batch["x_st"]), torch.from_numpy(batch["y_st"])
+    tr = training.Trainer(model, B, x_st.shape[1], ph, use_graph=False)
+    assert tr.engine.teacher_forced
+    loss = tr.step(x_st, y_st)
+    assert abs(float(loss) - float(z["train_loss"])) <= 1e-5 * abs(float(z["train_loss"]))
+    assert rel_err(tr.engine.predictions().numpy(), z["hist_pred"]) <= 1e-5
+    want = {k for k, v in meta["grad_norms"].items() if v is not None}
+    assert set(tr.engine.grad_by_name) == want
+    for name, g in tr.engine.grad_by_name.items():
+        assert rel_err(g.numpy(), z["grad::" + name]) <= GRAD_TOL, name
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            ok, e = check_post_step(p.detach().numpy(), z["post::" + key], z["grad::" + key] if "grad::" + key in z.files
+                                    else None, hp["learning_rate"])
+            assert ok, (key, e)
