@@ -250,6 +250,25 @@ int mmt_cumsum_axis(const float *x, long outer, int n, long inner, float *y, voi
 /* y += x (gradient of that cumsum walked backwards in time) */
 int mmt_add_inplace(float *y, const float *x, long n, void *stream);
 
+/* ---- GMM2D (Transformer/model/components/gmm2d.py:7-217; dead code in the live path, named by the north star) ----
+ * R = product of the leading dims, N = components (<= 64); mus / log_sigmas / sigmas (R,N,2), corrs & co (R,N).
+ * prepare = __init__ (:39-66): normalised log_pis, sigmas, clamp(1-rho^2), Cholesky L (R,N,2,2), covariance (:211-217);
+ * log_prob (:136-163) -> logp (R) and/or reg_los (:107-133) -> lreg (R,N);
+ * rsample (:79-105): out (S,R,2) = mu_c + L_c z_c, z (S,R,N,2) standard normal from the caller, component c from
+ *   comp (S,R) int32 or, when comp is NULL, by inverse CDF on the uniforms u (S,R); comp_out (S,R) optional;
+ * mode (:176-204): 0.01 mesh arg max between the component means, one (x,y) per distribution;
+ * from_cov (:68-77): covariance matrices (RN,2,2) -> log_sigmas (RN,2), corrs (RN). */
+int mmt_gmm2d_prepare(const float *log_pis, const float *log_sigmas, const float *corrs, long R, int N,
+                      float *norm_log_pis, float *sigmas, float *one_minus_rho2, float *L, float *cov, void *stream);
+int mmt_gmm2d_log_prob(const float *norm_log_pis, const float *mus, const float *log_sigmas, const float *sigmas,
+                       const float *corrs, const float *one_minus_rho2, const float *value, long R, int N,
+                       float *logp, float *lreg, void *stream);
+int mmt_gmm2d_rsample(const float *norm_log_pis, const float *mus, const float *L, const float *z, const int32_t *comp,
+                      const float *u, long S, long R, int N, float *out, int32_t *comp_out, void *stream);
+int mmt_gmm2d_mode(const float *norm_log_pis, const float *mus, const float *log_sigmas, const float *sigmas,
+                   const float *corrs, const float *one_minus_rho2, long R, int N, float *out, void *stream);
+int mmt_gmm2d_from_cov(const float *cov, long RN, float *log_sigmas, float *corrs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,9 +277,49 @@ def run_mlp():
     print("mlp_standalone", {k: v.shape for k, v in out.items() if "::y" in k})
 
 
+def run_gmm2d():
+    """Transformer/model/components/gmm2d.py (dead code in the live path, named by the north star): attributes,
+    log_prob, reg_los, covariance, from_log_pis_mus_cov_mats, mode (0.01 grid search) and rsample with the normal
+    noise / component draw pinned (torch.randn and Categorical.sample are replaced by stored tensors)."""
+    from model.components.gmm2d import GMM2D      # reference
+    import torch.distributions as td
+    g = torch.Generator().manual_seed(5)
+    S, Bn, Tn, N = 1, 3, 2, 4
+    log_pis = torch.randn(S, Bn, Tn, N, generator=g)
+    log_pis[0, 0, 0, 1] = -2e5                                     # exercises the clamp at -1e5
+    mus = torch.randn(S, Bn, Tn, N * 2, generator=g) * 0.15        # small spread: mode() grids of <= ~60 x 60 points
+    log_sigmas = torch.randn(S, Bn, Tn, N * 2, generator=g) * 0.3 - 1.5
+    corrs = torch.tanh(torch.randn(S, Bn, Tn, N, generator=g))
+    corrs[0, 1, 1, 2] = 0.9999999                                  # exercises the clamp of 1 - rho^2
+    value = torch.randn(S, Bn, Tn, 2, generator=g) * 0.2
+    gm = GMM2D(log_pis, mus, log_sigmas, corrs)
+    out = {"log_pis": log_pis.numpy(), "mus": mus.numpy(), "log_sigmas": log_sigmas.numpy(), "corrs": corrs.numpy(),
+           "value": value.numpy(), "norm_log_pis": gm.log_pis.numpy(), "sigmas": gm.sigmas.numpy(),
+           "one_minus_rho2": gm.one_minus_rho2.numpy(), "L": gm.L.numpy(), "log_prob": gm.log_prob(value).numpy(),
+           "reg_los": gm.reg_los(value).numpy(), "cov": gm.get_covariance_matrix().numpy(), "mode": gm.mode().numpy()}
+    gm2 = GMM2D.from_log_pis_mus_cov_mats(log_pis, mus, gm.get_covariance_matrix())
+    out["from_cov_log_sigmas"], out["from_cov_corrs"] = gm2.log_sigmas.numpy(), gm2.corrs.numpy()
+    # rsample with pinned randomness, sample_shape (5,)
+    z = torch.randn(5, S, Bn, Tn, N, 2, generator=g)
+    comp = torch.randint(0, N, (5, S, Bn, Tn), generator=g)
+    real_randn, real_sample = torch.randn, td.Categorical.sample
+    try:
+        torch.randn = lambda size, device=None: z
+        td.Categorical.sample = lambda self, sample_shape=torch.Size(): comp
+        out["rsample"] = gm.rsample(torch.Size([5])).numpy()
+    finally:
+        torch.randn, td.Categorical.sample = real_randn, real_sample
+    out["rsample_z"], out["rsample_comp"] = z.numpy(), comp.numpy()
+    # single component: mode() returns the mean
+    g1 = GMM2D(log_pis[..., :1], mus[..., :2], log_sigmas[..., :2], corrs[..., :1])
+    out["mode_single"] = g1.mode().numpy()
+    np.savez_compressed(os.path.join(HERE, "gmm2d.npz"), **out)
+    print("gmm2d", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["modes", "nonar", "mlp"]
+    what = sys.argv[1:] or ["modes", "nonar", "mlp", "gmm2d"]
     if "modes" in what:
         for tiny in (True, False):
             for mode in ("basic", "map_cnn", "lane_cnn"):
@@ -288,3 +328,5 @@ if __name__ == "__main__":
         run_nonar()
     if "mlp" in what:
         run_mlp()
+    if "gmm2d" in what:
+        run_gmm2d()

@@ -247,3 +247,47 @@ def test_vit_map_encoder_matches_cpu_restatement():
     hist, _ = model.predict(x, x_st, None, None, maps, 12)
     node = batch["x"][:, -1, 0:2][:, None, :]
     assert rel_err((hist.cpu().numpy() - node) / 80.0, (hist_want.numpy() - node) / 80.0) <= TOL
+
+
+def test_gmm2d_matches_reference_golden():
+    """Transformer/model/components/gmm2d.py (dead code in the live path, named by the north star): every attribute and
+    method against tensors produced by the reference class (tests/golden/gmm2d.npz; rsample with the normal noise and
+    the component draws pinned)."""
+    import os
+    from helpers import GOLDEN
+    from multimodal_transformer_amd.model.components import GMM2D
+    from multimodal_transformer_amd._lib import MmtError
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, "gmm2d.npz"))
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    g = GMM2D(t("log_pis"), t("mus"), t("log_sigmas"), t("corrs"))
+    for attr, key in (("log_pis", "norm_log_pis"), ("sigmas", "sigmas"), ("one_minus_rho2", "one_minus_rho2"), ("L", "L")):
+        assert rel_err(getattr(g, attr).cpu().numpy(), z[key]) <= 1e-5, attr
+    assert rel_err(g.get_covariance_matrix().cpu().numpy(), z["cov"]) <= 1e-5
+    assert rel_err(g.log_prob(t("value")).cpu().numpy(), z["log_prob"]) <= 1e-5
+    assert rel_err(g.reg_los(t("value")).cpu().numpy(), z["reg_los"]) <= 1e-5
+    got = g.rsample(torch.Size([5]), noise=t("rsample_z"), components=t("rsample_comp"))
+    assert got.shape == z["rsample"].shape and rel_err(got.cpu().numpy(), z["rsample"]) <= 1e-5
+    # the mesh has 0.01 spacing: the arg max may move by one cell where two cells tie to fp32 rounding
+    mode = g.mode().cpu().numpy()
+    assert mode.shape == z["mode"].shape and np.max(np.abs(mode - z["mode"])) <= 0.0101
+    lp_ours = g.log_prob(torch.from_numpy(mode).to(dev)).cpu().numpy()
+    lp_ref = g.log_prob(t("mode")).cpu().numpy()
+    assert np.all(lp_ours >= lp_ref - 1e-5)
+    g2 = GMM2D.from_log_pis_mus_cov_mats(t("log_pis"), t("mus"), t("cov"))
+    assert rel_err(g2.log_sigmas.cpu().numpy(), z["from_cov_log_sigmas"]) <= 1e-5
+    assert rel_err(g2.corrs.cpu().numpy(), z["from_cov_corrs"]) <= 1e-4
+    g1 = GMM2D(t("log_pis")[..., :1].contiguous(), t("mus")[..., :2].contiguous(), t("log_sigmas")[..., :2].contiguous(),
+               t("corrs")[..., :1].contiguous())
+    assert np.array_equal(g1.mode().cpu().numpy(), z["mode_single"])
+    # unpinned draw: inverse-CDF component selection follows the mixture weights
+    torch.manual_seed(0)
+    big = GMM2D(t("log_pis")[0, 0, 0].repeat(20000, 1), t("mus")[0, 0, 0].repeat(20000, 1),
+                t("log_sigmas")[0, 0, 0].repeat(20000, 1) - 20.0, t("corrs")[0, 0, 0].repeat(20000, 1))
+    s = big.rsample()
+    mus = z["mus"][0, 0, 0].reshape(-1, 2)
+    which = np.argmin(((s.cpu().numpy()[:, None, :] - mus[None]) ** 2).sum(-1), axis=1)
+    freq = np.bincount(which, minlength=4) / 20000.0
+    assert np.max(np.abs(freq - np.exp(z["norm_log_pis"][0, 0, 0]))) < 0.02
+    with pytest.raises(MmtError):
+        GMM2D(torch.zeros(2, 3), torch.zeros(2, 6), torch.zeros(2, 6), torch.zeros(2, 3))      # CPU tensors
