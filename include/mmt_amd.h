@@ -99,6 +99,9 @@ typedef struct {
   const float *fc_w, *fc_b;   /* plain row-major [n_out][flat] */
   int32_t n_out;
   int32_t input_affine;       /* 1: the kernel applies map*2-1 (mgcvae.py:290) while reading the raster */
+  /* optional: conv weights in MFMA lane order (mmt_pack_conv); with them the reference architecture
+   * (3x100x100 -> 10,k5,s2 -> 20,k5,s2 -> 10,k5,s1 -> 1,k3,s1) runs as implicit GEMM on the matrix cores */
+  const float *conv_wp[MMT_MAX_CONV];
 } mmt_cnn;
 
 /* Lane_Encoder: Lane_encoder.py:7-33 (Conv1d + leaky_relu + Linear) */
@@ -198,6 +201,10 @@ int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8
                         const float *start_pos, const float *map_feat, int map_dim,
                         const float *mem_feat, int mem_feat_dim, const float *tgt, int B, int T, int ph,
                         float *pred_st, float *h_out, float *workspace, void *stream);
+
+/* conv weight [Co][Ci][ks][ks] -> packed[tap][ci/4][co/16][lane = 16*(ci%4) + co%16], zero padded (new, no counterpart) */
+size_t mmt_packed_conv_floats(int Co, int Ci, int ks);
+int mmt_pack_conv(const float *w, int Co, int Ci, int ks, float *dst, void *stream);
 
 /* ---- CNNMapEncoder.forward on map*2-1 (map_encoder.py:31-36, mgcvae.py:288-290) ------------------ */
 size_t mmt_cnn_workspace_floats(const mmt_cnn *cnn, int B);

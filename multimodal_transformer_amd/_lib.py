@@ -58,7 +58,8 @@ class Cnn(C.Structure):
     _fields_ = [("nconv", C.c_int32), ("in_ch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
                 ("out_ch", C.c_int32 * MMT_MAX_CONV), ("ksize", C.c_int32 * MMT_MAX_CONV),
                 ("stride", C.c_int32 * MMT_MAX_CONV), ("conv_w", fptr * MMT_MAX_CONV), ("conv_b", fptr * MMT_MAX_CONV),
-                ("fc_w", fptr), ("fc_b", fptr), ("n_out", C.c_int32), ("input_affine", C.c_int32)]
+                ("fc_w", fptr), ("fc_b", fptr), ("n_out", C.c_int32), ("input_affine", C.c_int32),
+                ("conv_wp", fptr * MMT_MAX_CONV)]
 
 
 class Lane(C.Structure):
@@ -107,6 +108,8 @@ SIGNATURES = {
     "mmt_decoder_select": (C.c_int, [C.c_int]),
     "mmt_decoder_forward": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
                                       C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
+    "mmt_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mmt_pack_conv": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_cnn_workspace_floats": (C.c_size_t, [C.POINTER(Cnn), C.c_int]),
     "mmt_cnn_forward": (C.c_int, [C.POINTER(Cnn), fptr, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_vit_forward": (C.c_int, [C.POINTER(Vit), fptr, C.c_int, fptr, C.c_void_p]),

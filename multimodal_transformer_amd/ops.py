@@ -287,6 +287,16 @@ class PackedCnn:
         for j, (hw, hb) in enumerate(holders):
             N.conv_w[j], N.conv_b[j] = hw[0], hb[0]
         N.fc_w, N.fc_b = fw[0], fb[0]
+        # MFMA lane-ordered copies of the conv weights (used when the architecture is the reference's)
+        lib = _lib.load()
+        self.packed_convs = []
+        for j in range(N.nconv):
+            w = sd[f"convs.{j}.weight"].detach().contiguous()
+            dst = torch.empty(lib.mmt_packed_conv_floats(w.shape[0], w.shape[1], w.shape[2]), dtype=torch.float32,
+                              device=w.device)
+            _lib.check(lib.mmt_pack_conv(_ptr(w), w.shape[0], w.shape[1], w.shape[2], _ptr(dst), _stream()), "mmt_pack_conv")
+            self.packed_convs.append(dst)
+            N.conv_wp[j] = dst.data_ptr()
         self.desc = N
 
 
