@@ -276,6 +276,15 @@ int mmt_gmm2d_mode(const float *norm_log_pis, const float *mus, const float *log
                    const float *corrs, const float *one_minus_rho2, long R, int N, float *out, void *stream);
 int mmt_gmm2d_from_cov(const float *cov, long RN, float *log_sigmas, float *corrs, void *stream);
 
+/* ---- map patch extraction: GeometricMap.get_cropped_maps_from_scene_map_batch (environment/map.py:93-173)
+ * + warp_affine_crop / bilinear grid_sample (model/dataset/homography_warper.py:255-497) as one gather-rotate kernel.
+ * maps: device array of nmaps device pointers to uint8 rasters [layers][X][Y]; map_dims (nmaps,2) = X,Y; agent_map (B)
+ * = raster index per agent; centers (B,2) = the agents' map points (to_map_points, truncated to integers, unpadded);
+ * angles_deg (B) heading rotation in degrees or NULL; patch_size[4] = [-x,-y,+x,+y] (HOST pointer);
+ * out (B, layers, ps[1]+ps[3], ps[0]+ps[2]) fp32 in [0,1]. */
+int mmt_map_crop(const uint8_t *const *maps, const int32_t *map_dims, int layers, const int32_t *agent_map,
+                 const int32_t *centers, const float *angles_deg, const int32_t *patch_size, int B, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,7 @@ SIGNATURES = {
     "mmt_gmm2d_rsample": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_long, C.c_long, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_gmm2d_mode": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_long, C.c_int, fptr, C.c_void_p]),
     "mmt_gmm2d_from_cov": (C.c_int, [fptr, C.c_long, fptr, fptr, C.c_void_p]),
+    "mmt_map_crop": (C.c_int, [fptr, fptr, C.c_int, fptr, fptr, fptr, C.POINTER(C.c_int32), C.c_int, fptr, C.c_void_p]),
     "mmt_finalize": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, fptr, C.c_void_p]),
 }
 

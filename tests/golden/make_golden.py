@@ -317,9 +317,42 @@ def run_gmm2d():
     print("gmm2d", {k: v.shape for k, v in out.items()})
 
 
+def run_mapcrop():
+    """environment/map.py GeometricMap.get_cropped_maps_from_scene_map_batch (pad, crop, rotate with bilinear
+    grid_sample, slice) on two synthetic uint8 rasters: agents in the interior and at the borders (zero padding), with and without rotation, two patch sizes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_env_map", os.path.join(REF, "environment", "map.py"))
+    refmap = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(refmap)                   # reference
+    rng = np.random.default_rng(3)
+
+    def raster(X, Y):
+        base = rng.random((3, X // 8 + 2, Y // 8 + 2)) > 0.55            # blobs of ~8 px (a drivable-area-like mask)
+        up = np.repeat(np.repeat(base, 8, axis=1), 8, axis=2)[:, :X, :Y]
+        img = up.astype(np.uint8) * 255
+        img[1] = (rng.random((X, Y)) * 255).astype(np.uint8)             # one layer of per-pixel noise: hardest for bilinear parity
+        return img
+
+    maps = [refmap.GeometricMap(raster(420, 600), np.array([[3., 0., 12.], [0., 3., 7.], [0., 0., 1.]])),
+            refmap.GeometricMap(raster(333, 257), np.array([[2.5, 0., -20.], [0., 2.5, 31.], [0., 0., 1.]]))]
+    out = {"raster0": maps[0].data, "raster1": maps[1].data, "homography0": maps[0].homography, "homography1": maps[1].homography}
+    pts = np.array([[60.3, 90.7], [1.2, 2.9], [135.0, 195.5], [70.0, 10.0], [20.4, 40.6], [100.9, 60.1], [120.0, 80.0],
+                    [135.9, 195.9]])     # (the reference fails on agents outside their map: its crop slices come out short)
+    which = np.array([0, 0, 0, 0, 1, 1, 1, 0])
+    rot = torch.tensor([0., 33.3, -120.0, 90.0, 179.0, -15.5, 45.0, 271.25])
+    out["scene_pts"], out["which"], out["rotation"] = pts, which, rot.numpy()
+    for tag, ps in (("ref", [50, 10, 50, 90]), ("small", [8, 4, 6, 12])):
+        ml = [maps[w] for w in which]
+        out[f"{tag}::patch_size"] = np.array(ps)
+        out[f"{tag}::rotated"] = refmap.GeometricMap.get_cropped_maps_from_scene_map_batch(ml, torch.tensor(pts), ps, rotation=rot).numpy()
+        out[f"{tag}::unrotated"] = refmap.GeometricMap.get_cropped_maps_from_scene_map_batch(ml, torch.tensor(pts), ps, rotation=None).numpy()
+    np.savez_compressed(os.path.join(HERE, "mapcrop.npz"), **out)
+    print("mapcrop", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["modes", "nonar", "mlp", "gmm2d"]
+    what = sys.argv[1:] or ["modes", "nonar", "mlp", "gmm2d", "mapcrop"]
     if "modes" in what:
         for tiny in (True, False):
             for mode in ("basic", "map_cnn", "lane_cnn"):
@@ -330,3 +363,5 @@ if __name__ == "__main__":
         run_mlp()
     if "gmm2d" in what:
         run_gmm2d()
+    if "mapcrop" in what:
+        run_mapcrop()
