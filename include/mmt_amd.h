@@ -67,6 +67,9 @@ typedef struct {
   mmt_linear cq, ckv, cout;   /* cross attention: q (rows 0..d), kv (rows d..3d)   */
   mmt_linear ff1, ff2;
   mmt_norm ln1, ln2, ln3;
+  /* optional second copies in mmt_pack_linear4 order (NULL = absent): batches small enough for 4-agent clusters
+   * run their linears on the 4x4x1 matrix instruction, which reads this order */
+  const float *qkv4, *out4, *cq4, *cout4, *ff14, *ff24;
 } mmt_dec_layer;
 
 /* Mlp (MLP.py:6-30), regression form: n_hidden x (Linear, LayerNorm, ReLU) + Linear */
@@ -174,6 +177,9 @@ int mmt_version(void);
 size_t mmt_packed_linear_floats(int n, int k);
 /* W row-major [n][ldw]; columns [col0, col0+k) are packed (lets callers split in_proj / cat inputs) */
 int mmt_pack_linear(const float *w, int n, int k, int ldw, int col0, float *dst, void *stream);
+/* "4x4 block order" of the same rows/columns: dst[k/4][n/4][n%4][k%4], n*k floats; n and k multiples of 4.
+ * (No reference counterpart: nn.Linear keeps [n][k]; mmt_dec_layer.*4 point at such copies.) */
+int mmt_pack_linear4(const float *w, int n, int k, int ldw, int col0, float *dst, void *stream);
 
 /* ---- Encoder.forward  (Transformer_model.py:45-59; masks of model_utils.py:141-151 built in) --
  * x_st (B,T,n_in) may hold NaN padding; memory (B,T,d) out; pad_mask (B,T) uint8 out (may be NULL). */

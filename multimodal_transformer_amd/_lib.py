@@ -39,7 +39,8 @@ class Encoder(C.Structure):
 
 class DecLayer(C.Structure):
     _fields_ = [("qkv", Linear), ("out", Linear), ("cq", Linear), ("ckv", Linear), ("cout", Linear),
-                ("ff1", Linear), ("ff2", Linear), ("ln1", Norm), ("ln2", Norm), ("ln3", Norm)]
+                ("ff1", Linear), ("ff2", Linear), ("ln1", Norm), ("ln2", Norm), ("ln3", Norm),
+                ("qkv4", fptr), ("out4", fptr), ("cq4", fptr), ("cout4", fptr), ("ff14", fptr), ("ff24", fptr)]
 
 
 class Mlp(C.Structure):
@@ -103,6 +104,7 @@ SIGNATURES = {
     "mmt_version": (C.c_int, []),
     "mmt_packed_linear_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "mmt_pack_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "mmt_pack_linear4": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_encoder_forward": (C.c_int, [C.POINTER(Encoder), fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_decoder_workspace_floats": (C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     "mmt_decoder_select": (C.c_int, [C.c_int]),

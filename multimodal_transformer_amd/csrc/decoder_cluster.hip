@@ -21,6 +21,8 @@
 #include "mmt_gfx950.cuh"
 
 #include <algorithm>
+#include <cstddef>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -52,24 +54,35 @@ constexpr int KMAX = 16;          // most keys an attention sees (history / hori
 enum { XM_EMBED = 0, XM_REDUCE = 1, XM_HEAD_EMBED = 2 };
 enum { PH_A = 0, PH_B = 1, PH_C = 2, PH_H = 3 };
 
+// The first 160 bytes are what every launch needs before it can request anything from memory; the kernel pulls them
+// in with one batch of scalar loads (hot_args).  The host resolves the per-phase pointers.
 struct ClArgs {
   int B, T, ph, d, H, RC, s, L, n_in, n_out, FS16, map_dim, has_map_fusion, prof_idx;
+  int n_chain;                      // the small linears behind output_fc: fusion/hist_map then decoder/MLP
+  int pad0;
   const float *part_in, *xres_in;
   float *part_out, *xres_out;
   const float *red_bias;
   mmt_norm red_ln;
-  mmt_dec_layer W;
+  const float *w1, *b1, *w2;        // first linear (+ bias) and second linear of this phase, in the order the kernel variant reads
+  float *kv;                        // K/V cache of this phase: selfkv (A) or memkv (B)
+  const uint8_t *pad_mask;
   mmt_linear input_fc, output_fc;
   const float *pe;
-  int n_chain;                      // the small linears behind output_fc: fusion/hist_map then decoder/MLP
   mmt_linear chain[CHAIN_MAX];
   mmt_norm chain_ln[CHAIN_MAX];     // LayerNorm + ReLU after chain[i] when chain_ln[i].g != NULL
   const float *start_pos, *tgt, *map_feat;
   float *pred_st, *h_out;
-  const uint8_t *pad_mask;
-  const float *memkv;
-  float *selfkv;
 };
+static_assert(offsetof(ClArgs, input_fc) == 160, "hot block of ClArgs");
+
+// One batch of scalar loads for the hot block: left alone the compiler fetches each field where it is first needed,
+// which makes four or five dependent scalar-cache misses (~0.3 us each) before the first vector load can go out.
+__device__ __forceinline__ void hot_args(const ClArgs &a) {
+  asm volatile("" ::"s"(a.B), "s"(a.T), "s"(a.ph), "s"(a.d), "s"(a.H), "s"(a.RC), "s"(a.s), "s"(a.L), "s"(a.FS16), "s"(a.part_in),
+               "s"(a.xres_in), "s"(a.part_out), "s"(a.xres_out), "s"(a.red_bias), "s"(a.red_ln.g), "s"(a.red_ln.b), "s"(a.w1),
+               "s"(a.b1), "s"(a.w2), "s"(a.kv), "s"(a.pad_mask));
+}
 
 // ------------------------------------------------------------------------------- K-split linear
 // Y[16][16*S] = X[16][16*K16] W^T with the K range dealt over the waves (CPW chunks of 16 each): every wave
@@ -297,6 +310,18 @@ __device__ __forceinline__ void small_load(KsW<4, 1> &r, const mmt_linear &lin) 
   ks_load<4, 1>(r, lin.w, round16(lin.k) >> 4, round16(lin.n) >> 4, [](int s) { return s; });
 }
 
+// K/V cache rows of a cluster, staged through registers: unit u -> (agent, key, k|v, 16-byte piece) of the padded
+// [RC][KMAX][2][DH/4] index space (shifts only; the DH/4 lanes of a row read one contiguous 4*DH-byte line).
+template <int DH>
+__device__ __forceinline__ void kv_unit(int u, int &ag, int &j, int &kv, int &c4) {
+  static_assert(KMAX == 16, "kv_unit");
+  c4 = u % (DH / 4);
+  const int row = u / (DH / 4);
+  kv = row & 1;
+  j = (row >> 1) & 15;
+  ag = row >> 5;
+}
+
 // what a phase requests from memory for its own sub-layer
 template <int DH, int PHASE>
 struct PhaseGeom {      // register tiles sized per phase: every load instruction of the burst is a useful one
@@ -317,14 +342,14 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
   const int d = a.d, D16 = d >> 4, K16 = D16;
   constexpr int S_A = 3 * DH / 16, S_B = DH / 16;
   if constexpr (PHASE == PH_A) {
-    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.W.qkv.w, K16, S_A, [&](int s) { return (s / S_B) * D16 + g * S_B + (s % S_B); });
+    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.w1, K16, S_A, [&](int s) { return (s / S_B) * D16 + g * S_B + (s % S_B); });
   } else if constexpr (PHASE == PH_B) {
-    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.W.cq.w, K16, S_B, [&](int s) { return g * S_B + s; });
+    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.w1, K16, S_B, [&](int s) { return g * S_B + s; });
   } else {
-    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.W.ff1.w, K16, a.FS16, [&](int s) { return g * a.FS16 + s; });
+    ks_load<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, a.w1, K16, a.FS16, [&](int s) { return g * a.FS16 + s; });
   }
   const int S1 = PHASE == PH_A ? S_A : PHASE == PH_B ? S_B : a.FS16;
-  const rsrc_t rb1 = mk_rsrc(PHASE == PH_A ? a.W.qkv.b : PHASE == PH_B ? a.W.cq.b : a.W.ff1.b);
+  const rsrc_t rb1 = mk_rsrc(a.b1);
 #pragma unroll
   for (int it = 0; it < 3; ++it) {
     int row, col;
@@ -338,18 +363,14 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
   if constexpr (PHASE == PH_A || PHASE == PH_B) {
     // unit u -> (agent, key, k|v, 16-byte piece): the DH/4 lanes of a row read one contiguous 4*DH-byte line
     const int nglob = PHASE == PH_A ? a.s : a.T;
-    const int rows_per_agent = 2 * nglob, total = na * rows_per_agent * (DH / 4);
-    const float *base = PHASE == PH_A ? a.selfkv + (((size_t)a.L * a.B + a0) * a.ph) * 2 * d
-                                      : a.memkv + (((size_t)a.L * a.B + a0) * a.T) * 2 * d;
+    const float *base = a.kv + (((size_t)a.L * a.B + a0) * (PHASE == PH_A ? a.ph : a.T)) * 2 * d;
     const unsigned astride = (unsigned)(PHASE == PH_A ? a.ph : a.T) * 2 * d;
     const rsrc_t rkv = mk_rsrc(base);
-    const int rpa = max(rows_per_agent, 1);
 #pragma unroll
     for (int it = 0; it < DH / 4; ++it) {
-      const int u = threadIdx.x + CNT * it;
-      const int c4 = u % (DH / 4), row = u / (DH / 4), ag = row / rpa, rem = row - ag * rpa;
-      const int j = rem >> 1, kv = rem & 1;
-      M.kv[it] = bl4(rkv, u < total ? (ag * astride + (unsigned)j * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+      int ag, j, kv, c4;
+      kv_unit<DH>(threadIdx.x + CNT * it, ag, j, kv, c4);
+      M.kv[it] = bl4(rkv, (ag < na && j < nglob) ? (ag * astride + (unsigned)j * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
     }
   }
   M.pad = 0;
@@ -358,12 +379,163 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
     M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && threadIdx.x < 256 && ar < na && l16 < a.T)
                                                     ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
   }
-  if constexpr (PHASE == PH_A) ns_load(M.w2, a.W.out.w, K16, g * S_B, S_B, D16);
-  else if constexpr (PHASE == PH_B) ns_load(M.w2, a.W.cout.w, K16, g * S_B, S_B, D16);
-  else ns_load(M.w2, a.W.ff2.w, a.H * a.FS16, g * a.FS16, a.FS16, D16);
+  if constexpr (PHASE == PH_C) ns_load(M.w2, a.w2, a.H * a.FS16, g * a.FS16, a.FS16, D16);
+  else ns_load(M.w2, a.w2, K16, g * S_B, S_B, D16);
 }
 
-template <int DH, int CPW, int PHASE, int XMODE>
+
+// ------------------------------------------------------------------------------- 4-row clusters on v_mfma_f32_4x4x1
+// With RC = 4 agents a 16x16x4 tile is 3/4 padding and the phase is bound by MFMA issue (32 cycles per 64 weights).
+// v_mfma_f32_4x4x1_16B_f32 multiplies 16 independent 4x4 blocks in 8 cycles: block b = lanes 4b..4b+3 computes
+// D_b[i][j] += A_b[i] B_b[j] (lane 4b+j holds column j, register i holds row i).  A block is given the 4 agents as A
+// (every block reads x[l & 3][k]) and a group of 4 output columns as B, so one instruction retires 64 weights for 4
+// rows: 4x fewer matrix-core cycles.  The 128 block slots of a workgroup (8 waves x 16 blocks) are dealt as
+// (column group, K part); a slot runs over its K part in k-quads (one 16-byte weight load = 4 MFMAs), the K parts are
+// summed through LDS in fixed order.  Weights come from the "P4" layout [k/4][n/4][n%4][k%4] (mmt_pack_linear4) in
+// which the 16 blocks of a wave read two contiguous 512-byte runs per load instruction.
+template <int PHASE>
+struct Geom4 {
+  static constexpr int NPART = PHASE == PH_A ? 3 : 1;     // q | k | v
+  static constexpr int KQP1 = PHASE == PH_C ? 8 : 4;      // most k-quads per slot, first linear
+  static constexpr int KQP2 = PHASE == PH_C ? 8 : 4;      // second linear
+};
+template <int DH, int PHASE>
+struct MainRegs4 {
+  f32x4 w1[Geom4<PHASE>::NPART][Geom4<PHASE>::KQP1];
+  f32x4 w2[Geom4<PHASE>::KQP2];
+  float b1;
+  f32x4 kv[DH / 16];      // 4 agents: a quarter of the padded K/V index space
+  int pad;
+};
+struct Slot4 {
+  int cg, kq0, nkq;      // column group, first k-quad, k-quads of this slot (0 = idle)
+};
+// slot s of 128 -> (column group, K part) for NCG column groups and KQ k-quads; nkp = K parts in use
+__device__ __forceinline__ Slot4 slot4(int NCG, int KQ, int &nkp) {
+  // NCG and KQ are powers of two (mfma4_fits): shifts, no division
+  const int s = wave_id() * 16 + (lane_id() >> 2), lg = __builtin_ctz(NCG);
+  const int NKP = 128 >> lg, q = max(1, KQ >> __builtin_ctz(NKP));
+  nkp = min(NKP, KQ);
+  Slot4 r;
+  r.cg = s & (NCG - 1);
+  const int kp = s >> lg;
+  r.kq0 = kp * q;
+  r.nkq = kp < nkp ? q : 0;
+  return r;
+}
+
+template <int DH, int PHASE>
+__device__ __forceinline__ void main_issue4(MainRegs4<DH, PHASE> &M, const ClArgs &a, int a0, int na, int g) {
+  typedef Geom4<PHASE> G4;
+  const int d = a.d, KQ = d >> 2, FS = a.FS16 * 16, j4 = (lane_id() & 3) * 4;
+  const int NCG1 = PHASE == PH_C ? FS / 4 : DH / 4;
+  int nkp;
+  const Slot4 s1 = slot4(NCG1, KQ, nkp);
+  const int ncgfull = PHASE == PH_A ? 3 * d / 4 : PHASE == PH_B ? d / 4 : a.H * FS / 4;
+  const rsrc_t r1 = mk_rsrc(a.w1);
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p) {
+    const int cgg = (PHASE == PH_A ? (p * d + g * DH) / 4 : PHASE == PH_B ? g * DH / 4 : g * FS / 4) + s1.cg;
+#pragma unroll
+    for (int t = 0; t < G4::KQP1; ++t)
+      M.w1[p][t] = bl4(r1, t < s1.nkq ? (unsigned)(((s1.kq0 + t) * ncgfull + cgg) * 16 + j4) * 4u : OOB);
+  }
+  {   // bias of the first linear for this thread's reduction element (4 rows x N1 columns <= 512 elements)
+    const int N1 = G4::NPART * NCG1 * 4, col = PHASE == PH_C ? threadIdx.x & (N1 - 1) : threadIdx.x % N1;
+    int bi;
+    if constexpr (PHASE == PH_A) bi = (col / DH) * d + g * DH + (col % DH);
+    else if constexpr (PHASE == PH_B) bi = g * DH + col;
+    else bi = g * FS + col;
+    M.b1 = bl1(mk_rsrc(a.b1), (int)threadIdx.x < 4 * N1 ? (unsigned)bi * 4u : OOB);
+  }
+  if constexpr (PHASE == PH_A || PHASE == PH_B) {
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+    const float *base = a.kv + (((size_t)a.L * a.B + a0) * (PHASE == PH_A ? a.ph : a.T)) * 2 * d;
+    const unsigned astride = (unsigned)(PHASE == PH_A ? a.ph : a.T) * 2 * d;
+    const rsrc_t rkv = mk_rsrc(base);
+#pragma unroll
+    for (int it = 0; it < DH / 16; ++it) {
+      int ag, j, kv, c4;
+      kv_unit<DH>(threadIdx.x + CNT * it, ag, j, kv, c4);
+      M.kv[it] = bl4(rkv, (ag < na && j < nglob) ? (ag * astride + (unsigned)j * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+    }
+  }
+  M.pad = 0;
+  if constexpr (PHASE == PH_B) {
+    const int ar = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && threadIdx.x < 256 && ar < na && l16 < a.T)
+                                                    ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
+  }
+  {   // second linear: all d output columns, K slice [g*K2, (g+1)*K2) of out_proj / linear2
+    const int K2q = (PHASE == PH_C ? FS : DH) / 4;
+    const Slot4 s2 = slot4(d / 4, K2q, nkp);
+    const rsrc_t r2 = mk_rsrc(a.w2);
+#pragma unroll
+    for (int t = 0; t < G4::KQP2; ++t)
+      M.w2[t] = bl4(r2, t < s2.nkq ? (unsigned)(((g * K2q + s2.kq0 + t) * (d / 4) + s2.cg) * 16 + j4) * 4u : OOB);
+  }
+}
+
+// acc[p] (rows 0..3 in registers, column 4*cg + (lane & 3)) += x[l & 3][K part] W1 slice; partials -> red[kp][row][N1]
+template <int DH, int PHASE>
+__device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *xs, int ldx, float *red,
+                                        int &N1, int &nkp) {
+  typedef Geom4<PHASE> G4;
+  const int KQ = a.d >> 2, NCG1 = PHASE == PH_C ? a.FS16 * 4 : DH / 4;
+  N1 = G4::NPART * NCG1 * 4;
+  const Slot4 s1 = slot4(NCG1, KQ, nkp);
+  const int lane = lane_id();
+  const float *xr = xs + (lane & 3) * ldx;
+  f32x4 acc[G4::NPART];
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < G4::KQP1; ++t) {
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + 4 * min(s1.kq0 + t, KQ - 1));   // idle quads meet zero weights
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int p = 0; p < G4::NPART; ++p) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[e], M.w1[p][t][e], acc[p], 0, 0, 0);
+  }
+  if (s1.nkq > 0) {
+    const int kp = (wave_id() * 16 + (lane >> 2)) >> __builtin_ctz(NCG1);
+#pragma unroll
+    for (int p = 0; p < G4::NPART; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(kp * 4 + r) * N1 + p * NCG1 * 4 + s1.cg * 4 + (lane & 3)] = acc[p][r];
+  }
+}
+
+template <int DH, int PHASE>
+__device__ __forceinline__ void gemm2_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *x2, int ld2, float *red,
+                                        float *part) {
+  typedef Geom4<PHASE> G4;
+  const int d = a.d, K2q = (PHASE == PH_C ? a.FS16 * 16 : DH) / 4;
+  int nkp;
+  const Slot4 s2 = slot4(d / 4, K2q, nkp);
+  const int lane = lane_id();
+  const float *xr = x2 + (lane & 3) * ld2;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < G4::KQP2; ++t) {
+    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + 4 * min(s2.kq0 + t, K2q - 1));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[e], M.w2[t][e], acc, 0, 0, 0);
+  }
+  if (s2.nkq > 0) {
+    const int kp = (wave_id() * 16 + (lane >> 2)) >> __builtin_ctz(d / 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(kp * 4 + r) * d + s2.cg * 4 + (lane & 3)] = acc[r];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 4 * d; idx += CNT) {
+    float sum = 0.f;
+    for (int kp = 0; kp < nkp; ++kp) sum += red[kp * 4 * d + idx];
+    part[idx] = sum;            // rows 0..3, row stride d
+  }
+}
+
+template <int DH, int CPW, int PHASE, int XMODE, bool M4 = false>
 __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   extern __shared__ __align__(16) float smem[];
   const int d = a.d, ldx = d + MMT_PAD, D16 = d >> 4, K16 = D16;
@@ -389,21 +561,25 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   constexpr bool REDUCES = !(PHASE == PH_A && XMODE == XM_EMBED);
 
   CSTAMP(0);
+  hot_args(a);
   // ---- 1. one burst of requests: what the previous launch produced first, then this workgroup's own operands
   RedRegs R;                                        // deliberately not initialised: only waves with rows < RC touch it
   const bool red_wave = REDUCES && wave_id() * 2 < a.RC;   // wave-uniform (RC is even): idle waves issue nothing
   if (red_wave) reduce_issue(R, a, cluster);
-  MainRegs<DH, CPW, PHASE> M = {};
+  typename std::conditional<M4, MainRegs4<DH, PHASE>, MainRegs<DH, CPW, PHASE>>::type M = {};
   KsW<4, CPW> wo = {};
   KsW<4, 1> sm_cur = {};
   if constexpr (HEAD) {
     ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });
     if (!a.tgt) small_load(sm_cur, a.chain[0]);
   } else {
-    main_issue<DH, CPW, PHASE>(M, a, a0, na, g);     // (behind the head when there is one: its registers are busy)
+    if constexpr (M4) main_issue4<DH, PHASE>(M, a, a0, na, g);
+    else main_issue<DH, CPW, PHASE>(M, a, a0, na, g);   // (behind the head when there is one: its registers are busy)
   }
   CSTAMP(1);
-  for (int i = tid; i < 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256; i += CNT) t1[i] = 0.f;
+  // t1, ob and ps are written in full before they are read; the head's tiles and the token tile are not
+  if constexpr (HEAD || (PHASE == PH_A && XMODE != XM_REDUCE))
+    for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) ha[i] = 0.f;
   __syncthreads();
 
   // ---- 2. input of this sub-layer
@@ -466,7 +642,8 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
       }
     }
     if constexpr (PHASE == PH_H) return;
-    main_issue<DH, CPW, PHASE>(M, a, a0, na, g);
+    if constexpr (M4) main_issue4<DH, PHASE>(M, a, a0, na, g);
+    else main_issue<DH, CPW, PHASE>(M, a, a0, na, g);
     __syncthreads();
   }
   if constexpr (PHASE == PH_H) return;
@@ -484,14 +661,27 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
 
   CSTAMP(2);
   // ---- 3. first linear (K-split over the waves), bias (+ReLU) in the reduction
-  const int S1 = PHASE == PH_A ? S_A : PHASE == PH_B ? S_B : a.FS16;
-  ks_mfma<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, xs, ldx, K16, S1, red);
-  __syncthreads();
-  ks_reduce<CPW, 3>(red, K16, S1, [&](int r, int c, float v, int it) {
-    v += M.b1[it];
-    if (PHASE == PH_C) v = fmaxf(v, 0.f);
-    t1[r * LD1 + c] = v;
-  });
+  if constexpr (M4) {
+    int N1, nkp;
+    gemm1_4<DH, PHASE>(M, a, xs, ldx, red, N1, nkp);
+    __syncthreads();
+    if (tid < 4 * N1) {
+      float v = M.b1;
+      for (int kp = 0; kp < nkp; ++kp) v += red[kp * 4 * N1 + tid];
+      if (PHASE == PH_C) v = fmaxf(v, 0.f);
+      const int r = PHASE == PH_C ? tid >> __builtin_ctz(N1) : tid / N1;      // (N1 is a compile-time constant in A, B)
+      t1[r * LD1 + tid - r * N1] = v;
+    }
+  } else {
+    const int S1 = PHASE == PH_A ? S_A : PHASE == PH_B ? S_B : a.FS16;
+    ks_mfma<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, xs, ldx, K16, S1, red);
+    __syncthreads();
+    ks_reduce<CPW, 3>(red, K16, S1, [&](int r, int c, float v, int it) {
+      v += M.b1[it];
+      if (PHASE == PH_C) v = fmaxf(v, 0.f);
+      t1[r * LD1 + c] = v;
+    });
+  }
   CSTAMP(3);
 
   // ---- 4. attention of head g for the agents of the cluster, K/V staged in LDS
@@ -501,23 +691,18 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
     const int nglob = PHASE == PH_A ? a.s : a.T;
     const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
     __syncthreads();       // every wave is done reading `red`
-    {
-      const int rows_per_agent = 2 * nglob, total = na * rows_per_agent * (DH / 4);
 #pragma unroll
-      for (int it = 0; it < DH / 4; ++it) {
-        const int u = tid + CNT * it;
-        if (u < total) {
-          const int c4 = u % (DH / 4), row = u / (DH / 4), ag = row / rows_per_agent, rem = row - ag * rows_per_agent;
-          *reinterpret_cast<f32x4 *>(((rem & 1) ? Vs : Ks) + (ag * KMAX + (rem >> 1)) * LDK + 4 * c4) = M.kv[it];
-        }
-      }
+    for (int it = 0; it < (M4 ? DH / 16 : DH / 4); ++it) {
+      int ag, j, kv, c4;
+      kv_unit<DH>(tid + CNT * it, ag, j, kv, c4);
+      if (ag < na && j < nglob) *reinterpret_cast<f32x4 *>((kv ? Vs : Ks) + (ag * KMAX + j) * LDK + 4 * c4) = M.kv[it];
     }
     __syncthreads();       // t1 (q | k | v) complete
     if constexpr (PHASE == PH_A) {   // the new key / value: into the cache (read by later launches) and the staging tiles
       for (int i = tid; i < na * 2 * (DH / 4); i += CNT) {
         const int r = i / (2 * (DH / 4)), rem = i - r * 2 * (DH / 4), kv = rem / (DH / 4), c4 = rem - kv * (DH / 4);
         const f32x4 val = *reinterpret_cast<const f32x4 *>(t1 + r * LD1 + (1 + kv) * DH + 4 * c4);
-        *reinterpret_cast<f32x4 *>(a.selfkv + (((size_t)a.L * a.B + a0 + r) * a.ph + a.s) * 2 * d + kv * d + g * DH + 4 * c4) = val;
+        *reinterpret_cast<f32x4 *>(a.kv + (((size_t)a.L * a.B + a0 + r) * a.ph + a.s) * 2 * d + kv * d + g * DH + 4 * c4) = val;
         *reinterpret_cast<f32x4 *>((kv ? Vs : Ks) + (r * KMAX + a.s) * LDK + 4 * c4) = val;
       }
       __syncthreads();
@@ -569,7 +754,8 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   CSTAMP(4);
 
   // ---- 5. K-slice of the output projection: partial [RC][d] of this workgroup
-  ns_mfma_store(M.w2, x2, ld2, K2, D16, a.part_out + ((size_t)cluster * a.H + g) * 16 * d, d, a.RC);
+  if constexpr (M4) gemm2_4<DH, PHASE>(M, a, x2, ld2, red, a.part_out + ((size_t)cluster * a.H + g) * 16 * d);
+  else ns_mfma_store(M.w2, x2, ld2, K2, D16, a.part_out + ((size_t)cluster * a.H + g) * 16 * d, d, a.RC);
   CSTAMP(5);
 }
 
@@ -649,6 +835,22 @@ int cluster_rows(int B, int H) {
   return rc;
 }
 
+// 4-row clusters on the 4x4x1 path: P4 copies present and the slot split of every linear within the register budget.
+bool mfma4_fits(const mmt_decoder *dec) {
+  if (getenv("MMT_NO_MFMA4")) return false;
+  const int d = dec->d_model, H = dec->nhead, DH = d / H, FS = dec->d_ff / H, KQ = d / 4;
+  for (int l = 0; l < dec->nlayers; ++l) {
+    const mmt_dec_layer &W = dec->layer[l];
+    if (!W.qkv4 || !W.out4 || !W.cq4 || !W.cout4 || !W.ff14 || !W.ff24) return false;
+  }
+  auto quads = [](int ncg, int kq) { const int nkp = 128 / ncg; return (kq + nkp - 1) / nkp; };
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (!pow2(d / 4) || d / 4 > 128 || !pow2(DH / 4) || !pow2(FS / 4) || FS / 4 > 128) return false;
+  if (quads(DH / 4, KQ) > 4 || quads(FS / 4, KQ) > 8) return false;       // Geom4::KQP1
+  if (quads(d / 4, DH / 4) > 4 || quads(d / 4, FS / 4) > 8) return false;  // Geom4::KQP2
+  return true;
+}
+
 }  // namespace
 
 // Geometry the cluster kernels are written for; anything else runs on the persistent kernel.
@@ -680,8 +882,9 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
     if (e_ != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
   } while (0)
 
-template <int DH, int CPW>
-static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], hipStream_t st) {
+template <int DH, int CPW, bool M4>
+static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], float *memkv, float *selfkv,
+                         hipStream_t st) {
   const int d = dec->d_model, H = dec->nhead, NC = (B + a.RC - 1) / a.RC, L = dec->nlayers;
   constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
   const size_t lds_c = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256) * sizeof(float);
@@ -689,7 +892,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   static bool attr_done = false;
   if (!attr_done) {
 #define SET_LDS(PHASE, XM, BYTES) \
-  (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
+  (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM, M4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
     SET_LDS(PH_A, XM_EMBED, lds_a);
     SET_LDS(PH_A, XM_REDUCE, lds_a);
     SET_LDS(PH_A, XM_HEAD_EMBED, lds_a);
@@ -714,22 +917,33 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
     a.s = s;
     for (int l = 0; l < L; ++l) {
       a.L = l;
-      a.W = dec->layer[l];
+      const mmt_dec_layer &W = dec->layer[l];
       const mmt_dec_layer &prev = l == 0 ? last : dec->layer[l - 1];
+      a.w1 = M4 ? W.qkv4 : W.qkv.w;
+      a.b1 = W.qkv.b;
+      a.w2 = M4 ? W.out4 : W.out.w;
+      a.kv = selfkv;
       a.red_bias = prev.ff2.b;
       a.red_ln = prev.ln3;
       bufs(a);
-      if (l > 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_REDUCE>), grid, blk, lds_a, st, a);
-      else if (s == 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_EMBED>), grid, blk, lds_a, st, a);
-      else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_HEAD_EMBED>), grid, blk, lds_a, st, a);
-      a.red_bias = a.W.out.b;
-      a.red_ln = a.W.ln1;
+      if (l > 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_REDUCE, M4>), grid, blk, lds_a, st, a);
+      else if (s == 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_EMBED, M4>), grid, blk, lds_a, st, a);
+      else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_HEAD_EMBED, M4>), grid, blk, lds_a, st, a);
+      a.red_bias = W.out.b;
+      a.red_ln = W.ln1;
+      a.w1 = M4 ? W.cq4 : W.cq.w;
+      a.b1 = W.cq.b;
+      a.w2 = M4 ? W.cout4 : W.cout.w;
+      a.kv = memkv;
       bufs(a);
-      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_B, XM_REDUCE>), grid, blk, lds_a, st, a);
-      a.red_bias = a.W.cout.b;
-      a.red_ln = a.W.ln2;
+      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_B, XM_REDUCE, M4>), grid, blk, lds_a, st, a);
+      a.red_bias = W.cout.b;
+      a.red_ln = W.ln2;
+      a.w1 = M4 ? W.ff14 : W.ff1.w;
+      a.b1 = W.ff1.b;
+      a.w2 = M4 ? W.ff24 : W.ff2.w;
       bufs(a);
-      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_C, XM_REDUCE>), grid, blk, lds_c, st, a);
+      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_C, XM_REDUCE, M4>), grid, blk, lds_c, st, a);
     }
   }
   a.s = ph;
@@ -828,10 +1042,13 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   a.pred_st = pred_st;
   a.h_out = h_out;
   a.pad_mask = pad_mask;
-  a.memkv = memkv;
-  a.selfkv = selfkv;
   const int dh = d / H;
   const bool cpw2 = d > 128;
-  if (dh == 32) return cpw2 ? launch_phases<32, 2>(dec, a, B, ph, part, xres, st) : launch_phases<32, 1>(dec, a, B, ph, part, xres, st);
-  return cpw2 ? launch_phases<16, 2>(dec, a, B, ph, part, xres, st) : launch_phases<16, 1>(dec, a, B, ph, part, xres, st);
+  if (RC == 4 && mfma4_fits(dec)) {
+    // (CPW still sizes the K-split of the head's small linears, which stay on 16x16x4 tiles)
+    if (dh == 32) return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, st);
+    return cpw2 ? launch_phases<16, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<16, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, st);
+  }
+  if (dh == 32) return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, st);
+  return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, st);
 }

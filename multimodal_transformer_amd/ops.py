@@ -82,6 +82,16 @@ class _Packer:
         self.jobs.append(("lin", L, w, b, row0, col0, n, k, woff, boff))
         return L
 
+    def linear4(self, w, row0=0, n=None):
+        """Plan a 4x4-block-order copy (mmt_pack_linear4) of rows [row0,row0+n); None when the shape does not allow it."""
+        N, K = w.shape
+        n = N - row0 if n is None else n
+        if n % 4 or K % 4:
+            return None
+        holder = [None]
+        self.jobs.append(("lin4", holder, w, row0, n, K, self.arena.reserve(n * K)))
+        return holder
+
     def norm(self, g, b):
         goff = self.arena.reserve(_r16(g.numel()))
         boff = self.arena.reserve(_r16(b.numel()))
@@ -111,6 +121,12 @@ class _Packer:
                     L.b = A.addr(boff)
                 else:
                     L.b = None
+            elif job[0] == "lin4":
+                _, holder, w, row0, n, k, off = job
+                src = w.data_ptr() + 4 * row0 * w.shape[1]
+                _lib.check(self.lib.mmt_pack_linear4(C.c_void_p(src), n, k, w.shape[1], 0, C.c_void_p(A.addr(off)), st),
+                           "mmt_pack_linear4")
+                holder[0] = A.addr(off)
             elif job[0] == "norm":
                 _, Nn, g, b, goff, boff = job
                 A.buf[goff:goff + g.numel()].copy_(g.detach().reshape(-1))
@@ -210,7 +226,7 @@ class PackedDecoder:
         lin_in = pk.linear(w_in, sd["input_fc.bias"])
         lin_out = pk.linear(sd["output_fc.weight"], sd["output_fc.bias"])
         pe = pk.plain(sd["pos_encoder.pe"][:64])
-        layers = []
+        layers, blocks = [], []
         L = 0
         while f"transformer_decoder.layers.{L}.linear1.weight" in sd:
             p = f"transformer_decoder.layers.{L}."
@@ -226,6 +242,10 @@ class PackedDecoder:
                 ln1=pk.norm(sd[p + "norm1.weight"], sd[p + "norm1.bias"]),
                 ln2=pk.norm(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
                 ln3=pk.norm(sd[p + "norm3.weight"], sd[p + "norm3.bias"])))
+            blocks.append(dict(
+                qkv4=pk.linear4(sd[p + "self_attn.in_proj_weight"]), out4=pk.linear4(sd[p + "self_attn.out_proj.weight"]),
+                cq4=pk.linear4(cw, row0=0, n=d), cout4=pk.linear4(sd[p + "multihead_attn.out_proj.weight"]),
+                ff14=pk.linear4(sd[p + "linear1.weight"]), ff24=pk.linear4(sd[p + "linear2.weight"])))
             L += 1
         if L == 0 or L > _lib.MMT_MAX_LAYERS:
             raise MmtError(f"decoder with {L} layers is not supported (1..{_lib.MMT_MAX_LAYERS})")
@@ -246,6 +266,8 @@ class PackedDecoder:
         for i, lay in enumerate(layers):
             for k, v in lay.items():
                 _copy_struct(getattr(D.layer[i], k), v)
+            for k, h in blocks[i].items():
+                setattr(D.layer[i], k, h[0] if h is not None else None)
         if head is not None:
             _fill_mlp(D.head, head[1], head[2])
         D.has_map_fusion = int(mapf is not None)

@@ -40,7 +40,7 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(_lib.Linear) == 24
     assert ctypes.sizeof(_lib.Norm) == 16
     assert ctypes.sizeof(_lib.EncLayer) == 4 * 24 + 2 * 16
-    assert ctypes.sizeof(_lib.DecLayer) == 7 * 24 + 3 * 16
+    assert ctypes.sizeof(_lib.DecLayer) == 7 * 24 + 3 * 16 + 6 * 8
     assert ctypes.sizeof(_lib.Mlp) == 8 + 3 * 24 + 3 * 16 + 24
     assert ctypes.sizeof(_lib.Encoder) == 24 + 24 + 8 + 8 * ctypes.sizeof(_lib.EncLayer)
 
