@@ -67,8 +67,8 @@ typedef struct {
   mmt_linear cq, ckv, cout;   /* cross attention: q (rows 0..d), kv (rows d..3d)   */
   mmt_linear ff1, ff2;
   mmt_norm ln1, ln2, ln3;
-  /* optional second copies in mmt_pack_linear4 order (NULL = absent): batches small enough for 4-agent clusters
-   * run their linears on the 4x4x1 matrix instruction, which reads this order */
+  /* optional second copies in mmt_pack_lin4_first / _second order (NULL = absent): batches small enough for 4-agent
+   * clusters run their linears on the 4x4x1 matrix instruction, which reads this order */
   const float *qkv4, *out4, *cq4, *cout4, *ff14, *ff24;
 } mmt_dec_layer;
 
@@ -177,9 +177,18 @@ int mmt_version(void);
 size_t mmt_packed_linear_floats(int n, int k);
 /* W row-major [n][ldw]; columns [col0, col0+k) are packed (lets callers split in_proj / cat inputs) */
 int mmt_pack_linear(const float *w, int n, int k, int ldw, int col0, float *dst, void *stream);
-/* "4x4 block order" of the same rows/columns: dst[k/4][n/4][n%4][k%4], n*k floats; n and k multiples of 4.
- * (No reference counterpart: nn.Linear keeps [n][k]; mmt_dec_layer.*4 point at such copies.) */
-int mmt_pack_linear4(const float *w, int n, int k, int ldw, int col0, float *dst, void *stream);
+/* Copies of the decoder's linears for the 4-agent-cluster kernels (v_mfma_f32_4x4x1), laid out in the order those
+ * kernels' load instructions run: [slice][part][k-quad step][wave][lane][4].  "first" = a linear whose output rows are
+ * split over `nslices` workgroups (in_proj: nparts 3, part_rows d, slice_rows d/nhead; cross q: nparts 1; linear1:
+ * slice_rows d_ff/nhead), w = first row of the (nparts*part_rows or nslices*slice_rows) x k matrix, row stride ldw.
+ * "second" = a linear whose input columns are split (out_proj, linear2): n x (nslices*slice_k).
+ * *_floats returns 0 when the geometry is not one those kernels handle (the decoder then uses the 16-row kernels).
+ * No reference counterpart: nn.Linear keeps [n][k]; mmt_dec_layer.*4 point at such copies. */
+size_t mmt_lin4_first_floats(int nparts, int slice_rows, int k, int nslices);
+int mmt_pack_lin4_first(const float *w, int ldw, int nparts, int part_rows, int slice_rows, int k, int nslices, float *dst,
+                        void *stream);
+size_t mmt_lin4_second_floats(int n, int slice_k, int nslices);
+int mmt_pack_lin4_second(const float *w, int ldw, int n, int slice_k, int nslices, float *dst, void *stream);
 
 /* ---- Encoder.forward  (Transformer_model.py:45-59; masks of model_utils.py:141-151 built in) --
  * x_st (B,T,n_in) may hold NaN padding; memory (B,T,d) out; pad_mask (B,T) uint8 out (may be NULL). */

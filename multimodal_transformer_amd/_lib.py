@@ -104,7 +104,10 @@ SIGNATURES = {
     "mmt_version": (C.c_int, []),
     "mmt_packed_linear_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "mmt_pack_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
-    "mmt_pack_linear4": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "mmt_lin4_first_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mmt_pack_lin4_first": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "mmt_lin4_second_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mmt_pack_lin4_second": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_encoder_forward": (C.c_int, [C.POINTER(Encoder), fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_decoder_workspace_floats": (C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     "mmt_decoder_select": (C.c_int, [C.c_int]),

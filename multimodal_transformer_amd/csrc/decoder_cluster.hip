@@ -384,158 +384,66 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
 }
 
 
-// ------------------------------------------------------------------------------- 4-row clusters on v_mfma_f32_4x4x1
-// With RC = 4 agents a 16x16x4 tile is 3/4 padding and the phase is bound by MFMA issue (32 cycles per 64 weights).
-// v_mfma_f32_4x4x1_16B_f32 multiplies 16 independent 4x4 blocks in 8 cycles: block b = lanes 4b..4b+3 computes
-// D_b[i][j] += A_b[i] B_b[j] (lane 4b+j holds column j, register i holds row i).  A block is given the 4 agents as A
-// (every block reads x[l & 3][k]) and a group of 4 output columns as B, so one instruction retires 64 weights for 4
-// rows: 4x fewer matrix-core cycles.  The 128 block slots of a workgroup (8 waves x 16 blocks) are dealt as
-// (column group, K part); a slot runs over its K part in k-quads (one 16-byte weight load = 4 MFMAs), the K parts are
-// summed through LDS in fixed order.  Weights come from the "P4" layout [k/4][n/4][n%4][k%4] (mmt_pack_linear4) in
-// which the 16 blocks of a wave read two contiguous 512-byte runs per load instruction.
-template <int PHASE>
-struct Geom4 {
-  static constexpr int NPART = PHASE == PH_A ? 3 : 1;     // q | k | v
-  static constexpr int KQP1 = PHASE == PH_C ? 8 : 4;      // most k-quads per slot, first linear
-  static constexpr int KQP2 = PHASE == PH_C ? 8 : 4;      // second linear
-};
-template <int DH, int PHASE>
-struct MainRegs4 {
-  f32x4 w1[Geom4<PHASE>::NPART][Geom4<PHASE>::KQP1];
-  f32x4 w2[Geom4<PHASE>::KQP2];
-  float b1;
-  f32x4 kv[DH / 16];      // 4 agents: a quarter of the padded K/V index space
-  int pad;
-};
-struct Slot4 {
-  int cg, kq0, nkq;      // column group, first k-quad, k-quads of this slot (0 = idle)
-};
-// slot s of 128 -> (column group, K part) for NCG column groups and KQ k-quads; nkp = K parts in use
-__device__ __forceinline__ Slot4 slot4(int NCG, int KQ, int &nkp) {
-  // NCG and KQ are powers of two (mfma4_fits): shifts, no division
-  const int s = wave_id() * 16 + (lane_id() >> 2), lg = __builtin_ctz(NCG);
-  const int NKP = 128 >> lg, q = max(1, KQ >> __builtin_ctz(NKP));
-  nkp = min(NKP, KQ);
-  Slot4 r;
-  r.cg = s & (NCG - 1);
-  const int kp = s >> lg;
-  r.kq0 = kp * q;
-  r.nkq = kp < nkp ? q : 0;
-  return r;
-}
-
-template <int DH, int PHASE>
-__device__ __forceinline__ void main_issue4(MainRegs4<DH, PHASE> &M, const ClArgs &a, int a0, int na, int g) {
-  typedef Geom4<PHASE> G4;
-  const int d = a.d, KQ = d >> 2, FS = a.FS16 * 16, j4 = (lane_id() & 3) * 4;
-  const int NCG1 = PHASE == PH_C ? FS / 4 : DH / 4;
-  int nkp;
-  const Slot4 s1 = slot4(NCG1, KQ, nkp);
-  const int ncgfull = PHASE == PH_A ? 3 * d / 4 : PHASE == PH_B ? d / 4 : a.H * FS / 4;
-  const rsrc_t r1 = mk_rsrc(a.w1);
+// head of step hs = s - 1 on the LayerNorm'ed output of the last layer (xs): output_fc -> [fusion/hist_map] -> decoder/MLP ->
+// position feedback; leaves the next token in tok (autoregressive) and pred_st / h_out in global memory (workgroup g == 0).
+template <int CPW>
+__device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na, const float *xs, int ldx, float *red, float *ha,
+                                          float *hb, float *tok, const KsW<4, CPW> &wo, KsW<4, 1> sm_cur) {
+  // head of step hs = s - 1: output_fc -> [fusion/hist_map] -> decoder/MLP -> position feedback (mgcvae.py:435-446)
+  const int hs = a.s - 1, tid = threadIdx.x, K16 = a.d >> 4;
+  __syncthreads();
+  const int So = round16(a.n_out) >> 4;
+  ks_mfma<4, CPW>(wo, xs, ldx, K16, So, red);
+  if (!a.tgt && a.has_map_fusion)
+    for (int i = tid; i < na * a.map_dim; i += CNT) {
+      const int r = i / a.map_dim, c = i - r * a.map_dim;
+      ha[r * LDO + a.n_out + c] = a.map_feat[(size_t)(a0 + r) * a.map_dim + c];
+    }
+  __syncthreads();
+  ks_reduce<CPW, 2>(red, K16, So, [&](int r, int c, float v, int) {
+    if (c < a.n_out) {
+      v += a.output_fc.b[c];
+      ha[r * LDO + c] = v;
+      if (g == 0 && a.h_out && r < na) a.h_out[((size_t)(a0 + r) * a.ph + hs) * a.n_out + c] = v;
+    }
+  });
+  __syncthreads();
+  if (!a.tgt) {
+    float *cur = ha, *alt = hb;
 #pragma unroll
-  for (int p = 0; p < G4::NPART; ++p) {
-    const int cgg = (PHASE == PH_A ? (p * d + g * DH) / 4 : PHASE == PH_B ? g * DH / 4 : g * FS / 4) + s1.cg;
-#pragma unroll
-    for (int t = 0; t < G4::KQP1; ++t)
-      M.w1[p][t] = bl4(r1, t < s1.nkq ? (unsigned)(((s1.kq0 + t) * ncgfull + cgg) * 16 + j4) * 4u : OOB);
-  }
-  {   // bias of the first linear for this thread's reduction element (4 rows x N1 columns <= 512 elements)
-    const int N1 = G4::NPART * NCG1 * 4, col = PHASE == PH_C ? threadIdx.x & (N1 - 1) : threadIdx.x % N1;
-    int bi;
-    if constexpr (PHASE == PH_A) bi = (col / DH) * d + g * DH + (col % DH);
-    else if constexpr (PHASE == PH_B) bi = g * DH + col;
-    else bi = g * FS + col;
-    M.b1 = bl1(mk_rsrc(a.b1), (int)threadIdx.x < 4 * N1 ? (unsigned)bi * 4u : OOB);
-  }
-  if constexpr (PHASE == PH_A || PHASE == PH_B) {
-    const int nglob = PHASE == PH_A ? a.s : a.T;
-    const float *base = a.kv + (((size_t)a.L * a.B + a0) * (PHASE == PH_A ? a.ph : a.T)) * 2 * d;
-    const unsigned astride = (unsigned)(PHASE == PH_A ? a.ph : a.T) * 2 * d;
-    const rsrc_t rkv = mk_rsrc(base);
-#pragma unroll
-    for (int it = 0; it < DH / 16; ++it) {
-      int ag, j, kv, c4;
-      kv_unit<DH>(threadIdx.x + CNT * it, ag, j, kv, c4);
-      M.kv[it] = bl4(rkv, (ag < na && j < nglob) ? (ag * astride + (unsigned)j * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+    for (int i = 0; i < CHAIN_MAX; ++i) {
+      if (i < a.n_chain) {
+        KsW<4, 1> sm_nxt = sm_cur;
+        if (i + 1 < CHAIN_MAX && i + 1 < a.n_chain) small_load(sm_nxt, a.chain[i + 1 < CHAIN_MAX ? i + 1 : i]);
+        const int k16 = round16(a.chain[i].k) >> 4, s16 = round16(a.chain[i].n) >> 4, n = a.chain[i].n;
+        const float *bias = a.chain[i].b;
+        ks_mfma<4, 1>(sm_cur, cur, LDO, k16, s16, red);
+        __syncthreads();
+        ks_reduce<1, 2>(red, k16, s16, [&](int r, int c, float v, int) { alt[r * LDO + c] = c < n ? v + (bias ? bias[c] : 0.f) : 0.f; });
+        __syncthreads();
+        if (a.chain_ln[i].g) {
+          layer_norm_rows<true>(alt, LDO, 16, n, a.chain_ln[i]);
+          __syncthreads();
+        }
+        float *t = cur;
+        cur = alt;
+        alt = t;
+        sm_cur = sm_nxt;
+      }
+    }
+    // cur holds delta (n_in columns)
+    for (int i = tid; i < na * a.n_in; i += CNT) {
+      const int r = i / a.n_in, c = i - r * a.n_in;
+      const float prev = hs == 0 ? a.start_pos[(size_t)(a0 + r) * a.n_in + c]
+                                 : a.pred_st[((size_t)(a0 + r) * a.ph + hs - 1) * a.n_in + c];
+      const float np = prev + cur[r * LDO + c];
+      tok[r * LDTOK + c] = np;
+      if (g == 0) a.pred_st[((size_t)(a0 + r) * a.ph + hs) * a.n_in + c] = np;
     }
   }
-  M.pad = 0;
-  if constexpr (PHASE == PH_B) {
-    const int ar = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && threadIdx.x < 256 && ar < na && l16 < a.T)
-                                                    ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
-  }
-  {   // second linear: all d output columns, K slice [g*K2, (g+1)*K2) of out_proj / linear2
-    const int K2q = (PHASE == PH_C ? FS : DH) / 4;
-    const Slot4 s2 = slot4(d / 4, K2q, nkp);
-    const rsrc_t r2 = mk_rsrc(a.w2);
-#pragma unroll
-    for (int t = 0; t < G4::KQP2; ++t)
-      M.w2[t] = bl4(r2, t < s2.nkq ? (unsigned)(((g * K2q + s2.kq0 + t) * (d / 4) + s2.cg) * 16 + j4) * 4u : OOB);
-  }
 }
 
-// acc[p] (rows 0..3 in registers, column 4*cg + (lane & 3)) += x[l & 3][K part] W1 slice; partials -> red[kp][row][N1]
-template <int DH, int PHASE>
-__device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *xs, int ldx, float *red,
-                                        int &N1, int &nkp) {
-  typedef Geom4<PHASE> G4;
-  const int KQ = a.d >> 2, NCG1 = PHASE == PH_C ? a.FS16 * 4 : DH / 4;
-  N1 = G4::NPART * NCG1 * 4;
-  const Slot4 s1 = slot4(NCG1, KQ, nkp);
-  const int lane = lane_id();
-  const float *xr = xs + (lane & 3) * ldx;
-  f32x4 acc[G4::NPART];
-#pragma unroll
-  for (int p = 0; p < G4::NPART; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < G4::KQP1; ++t) {
-    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + 4 * min(s1.kq0 + t, KQ - 1));   // idle quads meet zero weights
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int p = 0; p < G4::NPART; ++p) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[e], M.w1[p][t][e], acc[p], 0, 0, 0);
-  }
-  if (s1.nkq > 0) {
-    const int kp = (wave_id() * 16 + (lane >> 2)) >> __builtin_ctz(NCG1);
-#pragma unroll
-    for (int p = 0; p < G4::NPART; ++p)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(kp * 4 + r) * N1 + p * NCG1 * 4 + s1.cg * 4 + (lane & 3)] = acc[p][r];
-  }
-}
-
-template <int DH, int PHASE>
-__device__ __forceinline__ void gemm2_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *x2, int ld2, float *red,
-                                        float *part) {
-  typedef Geom4<PHASE> G4;
-  const int d = a.d, K2q = (PHASE == PH_C ? a.FS16 * 16 : DH) / 4;
-  int nkp;
-  const Slot4 s2 = slot4(d / 4, K2q, nkp);
-  const int lane = lane_id();
-  const float *xr = x2 + (lane & 3) * ld2;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < G4::KQP2; ++t) {
-    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + 4 * min(s2.kq0 + t, K2q - 1));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[e], M.w2[t][e], acc, 0, 0, 0);
-  }
-  if (s2.nkq > 0) {
-    const int kp = (wave_id() * 16 + (lane >> 2)) >> __builtin_ctz(d / 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[(kp * 4 + r) * d + s2.cg * 4 + (lane & 3)] = acc[r];
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 4 * d; idx += CNT) {
-    float sum = 0.f;
-    for (int kp = 0; kp < nkp; ++kp) sum += red[kp * 4 * d + idx];
-    part[idx] = sum;            // rows 0..3, row stride d
-  }
-}
-
-template <int DH, int CPW, int PHASE, int XMODE, bool M4 = false>
+template <int DH, int CPW, int PHASE, int XMODE>
 __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   extern __shared__ __align__(16) float smem[];
   const int d = a.d, ldx = d + MMT_PAD, D16 = d >> 4, K16 = D16;
@@ -566,15 +474,14 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   RedRegs R;                                        // deliberately not initialised: only waves with rows < RC touch it
   const bool red_wave = REDUCES && wave_id() * 2 < a.RC;   // wave-uniform (RC is even): idle waves issue nothing
   if (red_wave) reduce_issue(R, a, cluster);
-  typename std::conditional<M4, MainRegs4<DH, PHASE>, MainRegs<DH, CPW, PHASE>>::type M = {};
+  MainRegs<DH, CPW, PHASE> M = {};
   KsW<4, CPW> wo = {};
   KsW<4, 1> sm_cur = {};
   if constexpr (HEAD) {
     ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });
     if (!a.tgt) small_load(sm_cur, a.chain[0]);
   } else {
-    if constexpr (M4) main_issue4<DH, PHASE>(M, a, a0, na, g);
-    else main_issue<DH, CPW, PHASE>(M, a, a0, na, g);   // (behind the head when there is one: its registers are busy)
+    main_issue<DH, CPW, PHASE>(M, a, a0, na, g);     // (behind the head when there is one: its registers are busy)
   }
   CSTAMP(1);
   // t1, ob and ps are written in full before they are read; the head's tiles and the token tile are not
@@ -589,61 +496,9 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
     for (int q = l32; q < (d >> 2); q += 32) *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   if constexpr (HEAD) {
-    // head of step hs = s - 1: output_fc -> [fusion/hist_map] -> decoder/MLP -> position feedback (mgcvae.py:435-446)
-    const int hs = a.s - 1;
-    __syncthreads();
-    const int So = round16(a.n_out) >> 4;
-    ks_mfma<4, CPW>(wo, xs, ldx, K16, So, red);
-    if (!a.tgt && a.has_map_fusion)
-      for (int i = tid; i < na * a.map_dim; i += CNT) {
-        const int r = i / a.map_dim, c = i - r * a.map_dim;
-        ha[r * LDO + a.n_out + c] = a.map_feat[(size_t)(a0 + r) * a.map_dim + c];
-      }
-    __syncthreads();
-    ks_reduce<CPW, 2>(red, K16, So, [&](int r, int c, float v, int) {
-      if (c < a.n_out) {
-        v += a.output_fc.b[c];
-        ha[r * LDO + c] = v;
-        if (g == 0 && a.h_out && r < na) a.h_out[((size_t)(a0 + r) * a.ph + hs) * a.n_out + c] = v;
-      }
-    });
-    __syncthreads();
-    if (!a.tgt) {
-      float *cur = ha, *alt = hb;
-#pragma unroll
-      for (int i = 0; i < CHAIN_MAX; ++i) {
-        if (i < a.n_chain) {
-          KsW<4, 1> sm_nxt = sm_cur;
-          if (i + 1 < CHAIN_MAX && i + 1 < a.n_chain) small_load(sm_nxt, a.chain[i + 1 < CHAIN_MAX ? i + 1 : i]);
-          const int k16 = round16(a.chain[i].k) >> 4, s16 = round16(a.chain[i].n) >> 4, n = a.chain[i].n;
-          const float *bias = a.chain[i].b;
-          ks_mfma<4, 1>(sm_cur, cur, LDO, k16, s16, red);
-          __syncthreads();
-          ks_reduce<1, 2>(red, k16, s16, [&](int r, int c, float v, int) { alt[r * LDO + c] = c < n ? v + (bias ? bias[c] : 0.f) : 0.f; });
-          __syncthreads();
-          if (a.chain_ln[i].g) {
-            layer_norm_rows<true>(alt, LDO, 16, n, a.chain_ln[i]);
-            __syncthreads();
-          }
-          float *t = cur;
-          cur = alt;
-          alt = t;
-          sm_cur = sm_nxt;
-        }
-      }
-      // cur holds delta (n_in columns)
-      for (int i = tid; i < na * a.n_in; i += CNT) {
-        const int r = i / a.n_in, c = i - r * a.n_in;
-        const float prev = hs == 0 ? a.start_pos[(size_t)(a0 + r) * a.n_in + c]
-                                   : a.pred_st[((size_t)(a0 + r) * a.ph + hs - 1) * a.n_in + c];
-        const float np = prev + cur[r * LDO + c];
-        tok[r * LDTOK + c] = np;
-        if (g == 0) a.pred_st[((size_t)(a0 + r) * a.ph + hs) * a.n_in + c] = np;
-      }
-    }
+    head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur);
     if constexpr (PHASE == PH_H) return;
-    if constexpr (M4) main_issue4<DH, PHASE>(M, a, a0, na, g);
-    else main_issue<DH, CPW, PHASE>(M, a, a0, na, g);
+    main_issue<DH, CPW, PHASE>(M, a, a0, na, g);
     __syncthreads();
   }
   if constexpr (PHASE == PH_H) return;
@@ -661,18 +516,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
 
   CSTAMP(2);
   // ---- 3. first linear (K-split over the waves), bias (+ReLU) in the reduction
-  if constexpr (M4) {
-    int N1, nkp;
-    gemm1_4<DH, PHASE>(M, a, xs, ldx, red, N1, nkp);
-    __syncthreads();
-    if (tid < 4 * N1) {
-      float v = M.b1;
-      for (int kp = 0; kp < nkp; ++kp) v += red[kp * 4 * N1 + tid];
-      if (PHASE == PH_C) v = fmaxf(v, 0.f);
-      const int r = PHASE == PH_C ? tid >> __builtin_ctz(N1) : tid / N1;      // (N1 is a compile-time constant in A, B)
-      t1[r * LD1 + tid - r * N1] = v;
-    }
-  } else {
+  {
     const int S1 = PHASE == PH_A ? S_A : PHASE == PH_B ? S_B : a.FS16;
     ks_mfma<PhaseGeom<DH, PHASE>::S1MAX, CPW>(M.w1, xs, ldx, K16, S1, red);
     __syncthreads();
@@ -692,7 +536,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
     const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
     __syncthreads();       // every wave is done reading `red`
 #pragma unroll
-    for (int it = 0; it < (M4 ? DH / 16 : DH / 4); ++it) {
+    for (int it = 0; it < DH / 4; ++it) {
       int ag, j, kv, c4;
       kv_unit<DH>(tid + CNT * it, ag, j, kv, c4);
       if (ag < na && j < nglob) *reinterpret_cast<f32x4 *>((kv ? Vs : Ks) + (ag * KMAX + j) * LDK + 4 * c4) = M.kv[it];
@@ -754,8 +598,355 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   CSTAMP(4);
 
   // ---- 5. K-slice of the output projection: partial [RC][d] of this workgroup
-  if constexpr (M4) gemm2_4<DH, PHASE>(M, a, x2, ld2, red, a.part_out + ((size_t)cluster * a.H + g) * 16 * d);
-  else ns_mfma_store(M.w2, x2, ld2, K2, D16, a.part_out + ((size_t)cluster * a.H + g) * 16 * d, d, a.RC);
+  ns_mfma_store(M.w2, x2, ld2, K2, D16, a.part_out + ((size_t)cluster * a.H + g) * 16 * d, d, a.RC);
+  CSTAMP(5);
+}
+
+// ------------------------------------------------------------------------------- 4-agent clusters on v_mfma_f32_4x4x1
+// With RC = 4 agents a 16x16x4 tile is 3/4 padding and the phase is bound by MFMA issue (32 cycles per 64 weights).
+// v_mfma_f32_4x4x1_16B_f32 multiplies 16 independent 4x4 blocks in 8 cycles: block b = lanes 4b..4b+3 computes
+// D_b[i][j] += A_b[i] B_b[j] (lane 4b+j holds column j, register i holds row i).  A block is given the 4 agents as A
+// (every block reads x[lane & 3][k]) and 4 output columns as B: 4x fewer matrix-core cycles.
+//
+// The 16 blocks of a wave are dealt as (column group, K part) with ALL K parts of a column group in one wave, so the
+// K parts are summed with DPP / permlane-swap adds inside the wave: no LDS round trip, no barrier.  Wave w owns the
+// column groups [w*cgw, (w+1)*cgw) (cgw = column groups / 8); block b -> column group b % cgw, K part b / cgw; a block
+// runs over q k-quads of its K part (one 16-byte weight load = 4 MFMAs).  The weights come from copies packed in
+// exactly the order (slice, part, k-quad step, wave, lane) the load instructions run in (mmt_pack_lin4_*): every wave
+// load is one contiguous KiB at a wave-uniform offset.
+struct Lin4 {      // geometry of one linear on the 4x4x1 path; all powers of two (mmt_lin4_*_floats checks)
+  int cgw, lg_cgw, q;
+};
+__host__ __device__ __forceinline__ Lin4 lin4(int col_groups, int kquads) {
+  Lin4 L;
+  L.cgw = col_groups >> 3;
+  L.lg_cgw = __builtin_ctz(L.cgw);
+  const int lg_nkp = 4 - L.lg_cgw;                   // K parts per column group = 16 / cgw
+  L.q = kquads >> lg_nkp;
+  if (L.q < 1) L.q = 1;                              // fewer k-quads than parts: the surplus blocks meet zero weights
+  return L;
+}
+// sum over the K parts of a column group: lanes that differ in the block bits above lg_cgw
+__device__ __forceinline__ float kparts_sum(float v, int cgw) {
+  if (cgw <= 1) v += dpp_mov<0x124>(v);              // row_ror:4
+  if (cgw <= 2) v += dpp_mov<0x128>(v);              // row_ror:8  (after ror:4 this covers all four rotations)
+  if (cgw <= 4) v = xor16_sum(v);
+  if (cgw <= 8) v = xor32_sum(v);
+  return v;
+}
+
+template <int PHASE>
+struct Geom4 {
+  static constexpr int NPART = PHASE == PH_A ? 3 : 1;     // q | k | v
+  static constexpr int QMAX1 = PHASE == PH_C ? 8 : 4;     // most k-quads per block, first linear
+  static constexpr int QMAX2 = PHASE == PH_C ? 8 : 4;     // second linear
+};
+template <int DH, int PHASE>
+struct MainRegs4 {
+  f32x4 w1[Geom4<PHASE>::NPART][Geom4<PHASE>::QMAX1];
+  f32x4 w2[Geom4<PHASE>::QMAX2];
+  float b1;               // bias of the first linear, on the lanes that write its result
+  f32x4 kv[DH / 16];      // 4 agents: a quarter of the padded K/V index space
+  int pad;
+};
+struct Red4Regs {
+  f32x4 res, bias, gam, bet, p[8];
+};
+
+// x = LN(res + bias + sum_g part[g]) for 4 rows: wave w < 4 owns row w, a lane one float4 (d <= 256).  Same summation order
+// over the parts as the 16-row version.
+__device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int cluster) {
+  const int row = wave_id(), q = lane_id();
+  const rsrc_t res = mk_rsrc(a.xres_in + ((size_t)cluster * 16 + row) * a.d), pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
+  const unsigned co = q < (a.d >> 2) ? (unsigned)q * 16u : OOB, gstride = 16u * a.d * 4u;
+  R.res = bl4(res, co);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) R.p[g] = bl4s(pp, g < a.H ? co : OOB, g < a.H ? g * gstride : 0u);
+  R.bias = bl4(mk_rsrc(a.red_bias), co);
+  R.gam = bl4(mk_rsrc(a.red_ln.g), co);
+  R.bet = bl4(mk_rsrc(a.red_ln.b), co);
+}
+__device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res) {
+  const int row = wave_id(), q = lane_id();
+  const bool live = q < (a.d >> 2);
+  f32x4 acc = R.res + R.bias;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) acc += R.p[g];          // unused slots hold zeros
+  const float mu = wave64_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) / (float)a.d;     // lanes beyond d/4 hold zeros
+  float var = 0.f;
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) var += (acc[e] - mu) * (acc[e] - mu);
+  }
+  const float rstd = 1.0f / sqrtf(wave64_sum(var) / (float)a.d + MMT_LN_EPS);
+  if (live) {
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (acc[e] - mu) * rstd * R.gam[e] + R.bet[e];
+    *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = y;
+    if (write_res) reinterpret_cast<f32x4 *>(a.xres_out + ((size_t)cluster * 16 + row) * a.d)[q] = y;
+  }
+}
+
+template <int DH, int PHASE>
+__device__ __forceinline__ void main_issue4(MainRegs4<DH, PHASE> &M, const ClArgs &a, int a0, int na, int g) {
+  typedef Geom4<PHASE> G4;
+  const int d = a.d, FS = a.FS16 * 16, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const unsigned lane_off = lane * 16u;
+  const Lin4 L1 = lin4((PHASE == PH_C ? FS : DH) / 4, d / 4);
+  const rsrc_t r1 = mk_rsrc(a.w1);
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p)
+#pragma unroll
+    for (int t = 0; t < G4::QMAX1; ++t)
+      M.w1[p][t] = bl4s(r1, t < L1.q ? lane_off : OOB, t < L1.q ? (unsigned)((((g * G4::NPART + p) * L1.q + t) * 8 + w) * 1024) : 0u);
+  {   // bias: the lanes of the first blocks write the result (block b -> part b in phase A, column group b else)
+    int bi;
+    if constexpr (PHASE == PH_A) bi = b * d + g * DH + w * 4 + j;
+    else if constexpr (PHASE == PH_B) bi = g * DH + w * 4 + j;
+    else bi = g * FS + (w * L1.cgw + b) * 4 + j;
+    M.b1 = bl1(mk_rsrc(a.b1), b < (PHASE == PH_C ? L1.cgw : G4::NPART) ? (unsigned)bi * 4u : OOB);
+  }
+  if constexpr (PHASE == PH_A || PHASE == PH_B) {
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+    const float *base = a.kv + (((size_t)a.L * a.B + a0) * (PHASE == PH_A ? a.ph : a.T)) * 2 * d;
+    const unsigned astride = (unsigned)(PHASE == PH_A ? a.ph : a.T) * 2 * d;
+    const rsrc_t rkv = mk_rsrc(base);
+#pragma unroll
+    for (int it = 0; it < DH / 16; ++it) {
+      int ag, jj, kv, c4;
+      kv_unit<DH>(threadIdx.x + CNT * it, ag, jj, kv, c4);
+      M.kv[it] = bl4(rkv, (ag < na && jj < nglob) ? (ag * astride + (unsigned)jj * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+    }
+  }
+  M.pad = 0;
+  if constexpr (PHASE == PH_B) {
+    const int ar = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && ar < na && l16 < a.T)
+                                                    ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
+  }
+  {   // second linear: all d output columns, K slice g of out_proj / linear2
+    const Lin4 L2 = lin4(d / 4, (PHASE == PH_C ? FS : DH) / 4);
+    const rsrc_t r2 = mk_rsrc(a.w2);
+#pragma unroll
+    for (int t = 0; t < G4::QMAX2; ++t)
+      M.w2[t] = bl4s(r2, t < L2.q ? lane_off : OOB, t < L2.q ? (unsigned)(((g * L2.q + t) * 8 + w) * 1024) : 0u);
+  }
+}
+
+// t1[0..3][columns of head g] = x W1slice^T + b (+ReLU in phase C)
+template <int DH, int PHASE>
+__device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *xs, int ldx, float *t1, int ld1) {
+  typedef Geom4<PHASE> G4;
+  const int KQ = a.d >> 2, FS = a.FS16 * 16, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const Lin4 L1 = lin4((PHASE == PH_C ? FS : DH) / 4, KQ);
+  const int kq0 = (b >> L1.lg_cgw) * L1.q;
+  const float *xr = xs + j * ldx;
+  f32x4 acc[G4::NPART];
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < G4::QMAX1; ++t) {
+    if (t < L1.q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + 4 * min(kq0 + t, KQ - 1));   // surplus blocks meet zero weights
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int p = 0; p < G4::NPART; ++p) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[e], M.w1[p][t][e], acc[p], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[p][r] = kparts_sum(acc[p][r], L1.cgw);
+  if constexpr (PHASE == PH_A) {
+    if (b < 3) {
+      const f32x4 v = b == 0 ? acc[0] : b == 1 ? acc[G4::NPART > 1 ? 1 : 0] : acc[G4::NPART > 2 ? 2 : 0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t1[r * ld1 + b * DH + w * 4 + j] = v[r] + M.b1;
+    }
+  } else if (b < (PHASE == PH_C ? L1.cgw : 1)) {
+    const int col = (w * L1.cgw + b) * 4 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t1[r * ld1 + col] = PHASE == PH_C ? fmaxf(acc[0][r] + M.b1, 0.f) : acc[0][r] + M.b1;
+  }
+}
+
+// part[0..3][d] = x2 W2slice^T (K slice g), straight from the accumulators to global memory
+template <int DH, int PHASE>
+__device__ __forceinline__ void gemm2_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *x2, int ld2, float *part) {
+  typedef Geom4<PHASE> G4;
+  const int d = a.d, K2q = (PHASE == PH_C ? a.FS16 * 16 : DH) / 4, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const Lin4 L2 = lin4(d / 4, K2q);
+  const int kq0 = (b >> L2.lg_cgw) * L2.q;
+  const float *xr = x2 + j * ld2;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < G4::QMAX2; ++t) {
+    if (t < L2.q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + 4 * min(kq0 + t, K2q - 1));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[e], M.w2[t][e], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = kparts_sum(acc[r], L2.cgw);
+  if (b < L2.cgw) {
+    const int col = (w * L2.cgw + b) * 4 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[r * d + col] = acc[r];
+  }
+}
+
+// Phase kernel for clusters of 4 agents (phases A, B, C; the head-only launch stays on mmt_dec_phase_kernel).
+template <int DH, int CPW, int PHASE, int XMODE>
+__global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
+  static_assert(DH == 32 && PHASE != PH_H, "4x4x1 path: 8 column groups per head, one per wave");
+  extern __shared__ __align__(16) float smem[];
+  const int d = a.d, ldx = d + MMT_PAD, K16 = d >> 4;
+  constexpr int LD1 = 3 * DH + 8;
+  constexpr int LDK = DH + 4;
+  float *xs = smem;                              // [16][ldx]   rows 0..3: LayerNorm'ed input (16 rows where the head runs)
+  float *red = xs + 16 * ldx;                    // K-split partial tiles of the head's small linears
+  float *t1 = red + CNW * KS_SMAX * 256;         // [4][LD1]    q|k|v of the head, or the FFN hidden slice
+  float *ob = t1 + 16 * LD1;                     // [4][LDO]    attention output of the head
+  float *ha = ob + 16 * LDO;
+  float *hb = ha + 16 * LDO;
+  float *tok = hb + 16 * LDO;
+  float *ps = tok + 16 * LDTOK;                  // [4][16]     attention probabilities
+  float *Ks = ps + 256;                          // [4][KMAX][LDK]
+  float *Vs = Ks + 4 * KMAX * LDK;               // [4][KMAX][LDK]
+  const int tid = threadIdx.x;
+  const int cluster = blockIdx.x / a.H, g = blockIdx.x - cluster * a.H;
+  const int a0 = cluster * 4, na = min(4, a.B - a0);
+  constexpr bool HEAD = XMODE == XM_HEAD_EMBED;
+  constexpr bool REDUCES = XMODE != XM_EMBED;
+  constexpr bool EMBEDS = PHASE == PH_A && XMODE != XM_REDUCE;
+
+  CSTAMP(0);
+  hot_args(a);
+  // ---- 1. one burst of requests
+  Red4Regs R;
+  const bool red_wave = REDUCES && wave_id() < 4;
+  if (red_wave) reduce4_issue(R, a, cluster);
+  MainRegs4<DH, PHASE> M = {};
+  KsW<4, CPW> wo = {};
+  KsW<4, 1> sm_cur = {};
+  if constexpr (HEAD) {
+    ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });
+    if (!a.tgt) small_load(sm_cur, a.chain[0]);
+  } else {
+    main_issue4<DH, PHASE>(M, a, a0, na, g);
+  }
+  CSTAMP(1);
+  if constexpr (EMBEDS) {                          // the head's 16-row tiles and the token tile must be finite
+    for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) ha[i] = 0.f;
+    if (HEAD && tid >= 256)                        // rows 4..15 of the head's input tile
+      for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
+        *reinterpret_cast<f32x4 *>(xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  }
+
+  // ---- 2. input of this sub-layer
+  if (red_wave) reduce4_finish(R, a, cluster, xs, ldx, g == 0 && !HEAD);
+  if constexpr (HEAD) {
+    head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur);
+    main_issue4<DH, PHASE>(M, a, a0, na, g);
+    __syncthreads();
+  }
+  if constexpr (EMBEDS) {
+    if (a.tgt || XMODE == XM_EMBED)
+      for (int i = tid; i < na * a.n_in; i += CNT) {
+        const int r = i / a.n_in, c = i - r * a.n_in;
+        tok[r * LDTOK + c] = a.tgt ? a.tgt[((size_t)(a0 + r) * a.ph + a.s) * a.n_in + c]
+                                   : a.start_pos[(size_t)(a0 + r) * a.n_in + c];
+      }
+    __syncthreads();
+    embed_token(a, cluster, tok, xs, ldx, g == 0);
+  }
+  __syncthreads();
+  CSTAMP(2);
+
+  // ---- 3. first linear; K/V cache rows from registers to their staging tiles
+  gemm1_4<DH, PHASE>(M, a, xs, ldx, t1, LD1);
+  if constexpr (PHASE != PH_C) {
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+#pragma unroll
+    for (int it = 0; it < DH / 16; ++it) {
+      int ag, j, kv, c4;
+      kv_unit<DH>(tid + CNT * it, ag, j, kv, c4);
+      if (ag < na && j < nglob) *reinterpret_cast<f32x4 *>((kv ? Vs : Ks) + (ag * KMAX + j) * LDK + 4 * c4) = M.kv[it];
+    }
+  }
+  __syncthreads();
+  CSTAMP(3);
+
+  // ---- 4. attention of head g: wave 0, one (agent, key) pair per lane; the key / value of this step come from t1
+  const float *x2 = t1;
+  int ld2 = LD1;
+  if constexpr (PHASE != PH_C) {
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+    const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
+    if (tid < 64) {
+      const int ar = tid >> 4, l16 = tid & 15;
+      float sc = -INFINITY;
+      bool masked = ar >= na || l16 >= nkeys;
+      if constexpr (PHASE == PH_B) masked = masked || M.pad != 0;
+      if (!masked) {
+        const float *q = t1 + ar * LD1;
+        const float *k = (PHASE == PH_A && l16 == nglob) ? q + DH : Ks + (ar * KMAX + l16) * LDK;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 4; ++c) {
+          const f32x4 qv = *reinterpret_cast<const f32x4 *>(q + 4 * c), kv4 = *reinterpret_cast<const f32x4 *>(k + 4 * c);
+          acc = fmaf(qv[0], kv4[0], acc);
+          acc = fmaf(qv[1], kv4[1], acc);
+          acc = fmaf(qv[2], kv4[2], acc);
+          acc = fmaf(qv[3], kv4[3], acc);
+        }
+        sc = acc * (1.0f / sqrtf((float)DH));
+      }
+      const float mx = row16_max(sc);
+      float p = mx > -INFINITY ? expf(sc - mx) : 0.f;    // a fully masked row yields zeros (reference: undefined / NaN)
+      const float sum = row16_sum(p);
+      p *= sum > 0.f ? 1.0f / sum : 0.f;
+      ps[tid] = p;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ps is written and read by this wave only
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr int DPL = DH / 16;
+      float o[DPL];
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+      const int nk = ar < na ? nglob : 0;
+      for (int j = 0; j < nk; ++j) {
+        const float pj = ps[ar * 16 + j];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, Vs[(ar * KMAX + j) * LDK + l16 * DPL + e], o[e]);
+      }
+      if (PHASE == PH_A && ar < na) {
+        const float pj = ps[ar * 16 + nglob];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, t1[ar * LD1 + 2 * DH + l16 * DPL + e], o[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) ob[ar * LDO + l16 * DPL + e] = o[e];
+    } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read by later launches)
+      const int i = tid - 256;
+      if (i < na * 2 * (DH / 4)) {
+        const int r = i / (2 * (DH / 4)), rem = i - r * 2 * (DH / 4), kv = rem / (DH / 4), c4 = rem - kv * (DH / 4);
+        *reinterpret_cast<f32x4 *>(a.kv + (((size_t)a.L * a.B + a0 + r) * a.ph + a.s) * 2 * d + kv * d + g * DH + 4 * c4) =
+            *reinterpret_cast<const f32x4 *>(t1 + r * LD1 + (1 + kv) * DH + 4 * c4);
+      }
+    }
+    x2 = ob;
+    ld2 = LDO;
+    __syncthreads();
+  }
+  CSTAMP(4);
+
+  // ---- 5. K-slice of the output projection: partial [4][d] of this workgroup
+  gemm2_4<DH, PHASE>(M, a, x2, ld2, a.part_out + ((size_t)cluster * a.H + g) * 16 * d);
   CSTAMP(5);
 }
 
@@ -835,23 +1026,80 @@ int cluster_rows(int B, int H) {
   return rc;
 }
 
-// 4-row clusters on the 4x4x1 path: P4 copies present and the slot split of every linear within the register budget.
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+bool lin4_first_ok(int slice_rows, int k) { return slice_rows % 4 == 0 && k % 4 == 0 && pow2(slice_rows / 4) && slice_rows >= 32 && slice_rows <= 512 && pow2(k / 4); }
+bool lin4_second_ok(int n, int slice_k) { return n % 4 == 0 && slice_k % 4 == 0 && pow2(n / 4) && n >= 32 && n <= 512 && pow2(slice_k / 4); }
+
+// 4-agent clusters on the 4x4x1 path: packed copies present and every linear within the kernels' register budget.
 bool mfma4_fits(const mmt_decoder *dec) {
   if (getenv("MMT_NO_MFMA4")) return false;
-  const int d = dec->d_model, H = dec->nhead, DH = d / H, FS = dec->d_ff / H, KQ = d / 4;
+  const int d = dec->d_model, H = dec->nhead, DH = d / H, FS = dec->d_ff / H;
   for (int l = 0; l < dec->nlayers; ++l) {
     const mmt_dec_layer &W = dec->layer[l];
     if (!W.qkv4 || !W.out4 || !W.cq4 || !W.cout4 || !W.ff14 || !W.ff24) return false;
   }
-  auto quads = [](int ncg, int kq) { const int nkp = 128 / ncg; return (kq + nkp - 1) / nkp; };
-  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-  if (!pow2(d / 4) || d / 4 > 128 || !pow2(DH / 4) || !pow2(FS / 4) || FS / 4 > 128) return false;
-  if (quads(DH / 4, KQ) > 4 || quads(FS / 4, KQ) > 8) return false;       // Geom4::KQP1
-  if (quads(d / 4, DH / 4) > 4 || quads(d / 4, FS / 4) > 8) return false;  // Geom4::KQP2
+  if (DH != 32 || !lin4_first_ok(DH, d) || !lin4_first_ok(FS, d) || !lin4_second_ok(d, DH) || !lin4_second_ok(d, FS)) return false;
+  if (lin4(DH / 4, d / 4).q > 4 || lin4(FS / 4, d / 4).q > 8) return false;       // Geom4::QMAX1
+  if (lin4(d / 4, DH / 4).q > 4 || lin4(d / 4, FS / 4).q > 8) return false;       // Geom4::QMAX2
   return true;
 }
 
+__global__ void mmt_pack_lin4_first_kernel(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
+                                           size_t total, float *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const Lin4 L = lin4(slice_rows / 4, k / 4);
+  const int e = i & 3, lane = (i >> 2) & 63, wv = (i >> 8) & 7;
+  size_t rest = i >> 11;
+  const int t = rest % L.q;
+  rest /= L.q;
+  const int p = rest % nparts, g = rest / nparts;
+  const int b = lane >> 2, j = lane & 3, cgl = b & (L.cgw - 1), kq = (b >> L.lg_cgw) * L.q + t;
+  const int row = p * part_rows + g * slice_rows + (wv * L.cgw + cgl) * 4 + j;
+  dst[i] = kq < k / 4 ? w[(size_t)row * ldw + 4 * kq + e] : 0.f;
+}
+__global__ void mmt_pack_lin4_second_kernel(const float *__restrict__ w, int ldw, int n, int slice_k, size_t total,
+                                            float *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const Lin4 L = lin4(n / 4, slice_k / 4);
+  const int e = i & 3, lane = (i >> 2) & 63, wv = (i >> 8) & 7;
+  const size_t rest = i >> 11;
+  const int t = rest % L.q, g = rest / L.q;
+  const int b = lane >> 2, j = lane & 3, cgl = b & (L.cgw - 1), kq = (b >> L.lg_cgw) * L.q + t;
+  const int row = (wv * L.cgw + cgl) * 4 + j;
+  dst[i] = kq < slice_k / 4 ? w[(size_t)row * ldw + (size_t)g * slice_k + 4 * kq + e] : 0.f;
+}
+
 }  // namespace
+
+extern "C" size_t mmt_lin4_first_floats(int nparts, int slice_rows, int k, int nslices) {
+  if (nparts < 1 || nslices < 1 || !lin4_first_ok(slice_rows, k)) return 0;
+  return (size_t)nslices * nparts * lin4(slice_rows / 4, k / 4).q * 2048;
+}
+extern "C" int mmt_pack_lin4_first(const float *w, int ldw, int nparts, int part_rows, int slice_rows, int k, int nslices, float *dst,
+                                   void *stream) {
+  const size_t total = mmt_lin4_first_floats(nparts, slice_rows, k, nslices);
+  if (!w || !dst || !total || ldw < k || (nparts > 1 && part_rows < nslices * slice_rows))
+    return mmt_set_error(MMT_EINVAL, "mmt_pack_lin4_first: bad arguments or unsupported geometry");
+  hipLaunchKernelGGL(mmt_pack_lin4_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, nparts,
+                     part_rows, slice_rows, k, total, dst);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : mmt_set_error(MMT_ELAUNCH, "mmt_pack_lin4_first: %s", hipGetErrorString(e));
+}
+extern "C" size_t mmt_lin4_second_floats(int n, int slice_k, int nslices) {
+  if (nslices < 1 || !lin4_second_ok(n, slice_k)) return 0;
+  return (size_t)nslices * lin4(n / 4, slice_k / 4).q * 2048;
+}
+extern "C" int mmt_pack_lin4_second(const float *w, int ldw, int n, int slice_k, int nslices, float *dst, void *stream) {
+  const size_t total = mmt_lin4_second_floats(n, slice_k, nslices);
+  if (!w || !dst || !total || ldw < nslices * slice_k)
+    return mmt_set_error(MMT_EINVAL, "mmt_pack_lin4_second: bad arguments or unsupported geometry");
+  hipLaunchKernelGGL(mmt_pack_lin4_second_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, ldw, n, slice_k,
+                     total, dst);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : mmt_set_error(MMT_ELAUNCH, "mmt_pack_lin4_second: %s", hipGetErrorString(e));
+}
 
 // Geometry the cluster kernels are written for; anything else runs on the persistent kernel.
 bool mmt_cluster_decoder_supports(const mmt_decoder *dec, int map_dim, bool autoregressive, int T, int ph) {
@@ -891,8 +1139,13 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   const size_t lds_a = lds_c + (size_t)16 * KMAX * (DH + 4) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-#define SET_LDS(PHASE, XM, BYTES) \
-  (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM, M4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))
+#define SET_LDS(PHASE, XM, BYTES)                                                                                                     \
+  do {                                                                                                                                \
+    (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
+    if constexpr (M4 && PHASE != PH_H)                                                                                                \
+      (void)hipFuncSetAttribute((const void *)mmt_dec_phase4_kernel<DH, CPW, PHASE == PH_H ? PH_C : PHASE, XM>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));                                            \
+  } while (0)
     SET_LDS(PH_A, XM_EMBED, lds_a);
     SET_LDS(PH_A, XM_REDUCE, lds_a);
     SET_LDS(PH_A, XM_HEAD_EMBED, lds_a);
@@ -902,6 +1155,11 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 #undef SET_LDS
     attr_done = true;
   }
+#define LAUNCH_PHASE(PHASE, XM, BYTES)                                                                     \
+  do {                                                                                                     \
+    if constexpr (M4) hipLaunchKernelGGL((mmt_dec_phase4_kernel<DH, CPW, PHASE, XM>), grid, blk, BYTES, st, a); \
+    else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PHASE, XM>), grid, blk, BYTES, st, a);          \
+  } while (0)
   int p = 0;   // phase counter: phase p writes part[p&1] / xres[p&1] and reads the other pair
   auto bufs = [&](ClArgs &x) {
     x.part_out = part[p & 1];
@@ -926,9 +1184,9 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       a.red_bias = prev.ff2.b;
       a.red_ln = prev.ln3;
       bufs(a);
-      if (l > 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_REDUCE, M4>), grid, blk, lds_a, st, a);
-      else if (s == 0) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_EMBED, M4>), grid, blk, lds_a, st, a);
-      else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_A, XM_HEAD_EMBED, M4>), grid, blk, lds_a, st, a);
+      if (l > 0) LAUNCH_PHASE(PH_A, XM_REDUCE, lds_a);
+      else if (s == 0) LAUNCH_PHASE(PH_A, XM_EMBED, lds_a);
+      else LAUNCH_PHASE(PH_A, XM_HEAD_EMBED, lds_a);
       a.red_bias = W.out.b;
       a.red_ln = W.ln1;
       a.w1 = M4 ? W.cq4 : W.cq.w;
@@ -936,14 +1194,14 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       a.w2 = M4 ? W.cout4 : W.cout.w;
       a.kv = memkv;
       bufs(a);
-      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_B, XM_REDUCE, M4>), grid, blk, lds_a, st, a);
+      LAUNCH_PHASE(PH_B, XM_REDUCE, lds_a);
       a.red_bias = W.cout.b;
       a.red_ln = W.ln2;
       a.w1 = M4 ? W.ff14 : W.ff1.w;
       a.b1 = W.ff1.b;
       a.w2 = M4 ? W.ff24 : W.ff2.w;
       bufs(a);
-      hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_C, XM_REDUCE, M4>), grid, blk, lds_c, st, a);
+      LAUNCH_PHASE(PH_C, XM_REDUCE, lds_c);
     }
   }
   a.s = ph;
@@ -951,6 +1209,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   a.red_ln = last.ln3;
   bufs(a);
   hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_H, XM_REDUCE>), dim3(NC), blk, lds_c, st, a);
+#undef LAUNCH_PHASE
   CL_CHECK("mmt_decoder_forward (cluster phases)");
   return MMT_OK;
 }
@@ -1046,8 +1305,7 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   const bool cpw2 = d > 128;
   if (RC == 4 && mfma4_fits(dec)) {
     // (CPW still sizes the K-split of the head's small linears, which stay on 16x16x4 tiles)
-    if (dh == 32) return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, st);
-    return cpw2 ? launch_phases<16, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<16, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, st);
+    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, st);
   }
   if (dh == 32) return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, st);
   return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, st);

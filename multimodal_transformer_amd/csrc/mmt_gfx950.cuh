@@ -16,6 +16,10 @@ __device__ __forceinline__ rsrc_t mk_rsrc(const void *p) {
 __device__ __forceinline__ f32x4 bl4(rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// same with a wave-uniform part of the offset in an SGPR (not range-checked: push `byte_off` out of range to skip)
+__device__ __forceinline__ f32x4 bl4s(rsrc_t r, unsigned byte_off, unsigned uniform_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, uniform_off, 0));
+}
 __device__ __forceinline__ float bl1(rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
@@ -40,3 +44,19 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x140>(v);
   return v;
 }
+
+// ---- sums across the four DPP rows of a wave --------------------------------------------------------------
+// v_permlane{16,32}_swap exchange half of the rows between two registers; fed the same value twice they leave the
+// two registers holding lane l and lane l^16 (l^32) between them.  (Inline asm: the builtin pairs the results wrongly
+// in this compiler.  s_nop 1 covers the VALU-write -> permlane-swap-read hazard the assembler does not see.)
+__device__ __forceinline__ float xor16_sum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }

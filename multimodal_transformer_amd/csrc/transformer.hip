@@ -395,20 +395,6 @@ extern "C" int mmt_debug_read_prof(unsigned long long *host, int n) {
 }
 #endif
 
-__global__ void mmt_pack_linear4_kernel(const float *__restrict__ w, int n, int k, int ldw, int col0, float *__restrict__ dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * k) return;
-  const int e = i & 3, j = (i >> 2) & 3, blk = i >> 4, cg = blk % (n >> 2), kq = blk / (n >> 2);
-  dst[i] = w[(size_t)(4 * cg + j) * ldw + col0 + 4 * kq + e];
-}
-
-extern "C" int mmt_pack_linear4(const float *w, int n, int k, int ldw, int col0, float *dst, void *stream) {
-  if (!w || !dst || n <= 0 || k <= 0 || (n & 3) || (k & 3) || ldw < col0 + k || col0 < 0)
-    return fail(MMT_EINVAL, "mmt_pack_linear4: bad arguments (n and k must be multiples of 4)");
-  hipLaunchKernelGGL(mmt_pack_linear4_kernel, dim3((n * k + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, n, k, ldw, col0, dst);
-  return check_launch("mmt_pack_linear4");
-}
-
 extern "C" size_t mmt_packed_linear_floats(int n, int k) {
   return (size_t)((n + 15) & ~15) * (size_t)((k + 15) & ~15);
 }

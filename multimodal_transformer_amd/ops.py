@@ -82,14 +82,23 @@ class _Packer:
         self.jobs.append(("lin", L, w, b, row0, col0, n, k, woff, boff))
         return L
 
-    def linear4(self, w, row0=0, n=None):
-        """Plan a 4x4-block-order copy (mmt_pack_linear4) of rows [row0,row0+n); None when the shape does not allow it."""
-        N, K = w.shape
-        n = N - row0 if n is None else n
-        if n % 4 or K % 4:
+    def lin4_first(self, w, nparts, part_rows, slice_rows, nslices):
+        """Plan a copy of a row-split linear in the order of the 4-agent-cluster kernels (mmt_pack_lin4_first); None when
+        the geometry is not one they handle.  ``w`` starts at the first row used (a view is fine, row stride = w.stride(0))."""
+        n = self.lib.mmt_lin4_first_floats(nparts, slice_rows, w.shape[1], nslices)
+        if not n:
             return None
         holder = [None]
-        self.jobs.append(("lin4", holder, w, row0, n, K, self.arena.reserve(n * K)))
+        self.jobs.append(("lin4a", holder, w, nparts, part_rows, slice_rows, nslices, self.arena.reserve(n)))
+        return holder
+
+    def lin4_second(self, w, slice_k, nslices):
+        """Same for a column-split linear (out_proj, linear2): mmt_pack_lin4_second."""
+        n = self.lib.mmt_lin4_second_floats(w.shape[0], slice_k, nslices)
+        if not n or w.shape[1] != slice_k * nslices:
+            return None
+        holder = [None]
+        self.jobs.append(("lin4b", holder, w, slice_k, nslices, self.arena.reserve(n)))
         return holder
 
     def norm(self, g, b):
@@ -121,11 +130,15 @@ class _Packer:
                     L.b = A.addr(boff)
                 else:
                     L.b = None
-            elif job[0] == "lin4":
-                _, holder, w, row0, n, k, off = job
-                src = w.data_ptr() + 4 * row0 * w.shape[1]
-                _lib.check(self.lib.mmt_pack_linear4(C.c_void_p(src), n, k, w.shape[1], 0, C.c_void_p(A.addr(off)), st),
-                           "mmt_pack_linear4")
+            elif job[0] == "lin4a":
+                _, holder, w, nparts, part_rows, slice_rows, nslices, off = job
+                _lib.check(self.lib.mmt_pack_lin4_first(C.c_void_p(w.data_ptr()), w.stride(0), nparts, part_rows, slice_rows,
+                                                        w.shape[1], nslices, C.c_void_p(A.addr(off)), st), "mmt_pack_lin4_first")
+                holder[0] = A.addr(off)
+            elif job[0] == "lin4b":
+                _, holder, w, slice_k, nslices, off = job
+                _lib.check(self.lib.mmt_pack_lin4_second(C.c_void_p(w.data_ptr()), w.stride(0), w.shape[0], slice_k, nslices,
+                                                         C.c_void_p(A.addr(off)), st), "mmt_pack_lin4_second")
                 holder[0] = A.addr(off)
             elif job[0] == "norm":
                 _, Nn, g, b, goff, boff = job
@@ -242,10 +255,18 @@ class PackedDecoder:
                 ln1=pk.norm(sd[p + "norm1.weight"], sd[p + "norm1.bias"]),
                 ln2=pk.norm(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
                 ln3=pk.norm(sd[p + "norm3.weight"], sd[p + "norm3.bias"])))
-            blocks.append(dict(
-                qkv4=pk.linear4(sd[p + "self_attn.in_proj_weight"]), out4=pk.linear4(sd[p + "self_attn.out_proj.weight"]),
-                cq4=pk.linear4(cw, row0=0, n=d), cout4=pk.linear4(sd[p + "multihead_attn.out_proj.weight"]),
-                ff14=pk.linear4(sd[p + "linear1.weight"]), ff24=pk.linear4(sd[p + "linear2.weight"])))
+            f = sd[p + "linear1.weight"].shape[0]
+            if d % nhead == 0 and f % nhead == 0:
+                dh, fs = d // nhead, f // nhead
+                blocks.append(dict(
+                    qkv4=pk.lin4_first(sd[p + "self_attn.in_proj_weight"], 3, d, dh, nhead),
+                    out4=pk.lin4_second(sd[p + "self_attn.out_proj.weight"], dh, nhead),
+                    cq4=pk.lin4_first(cw[:d], 1, 0, dh, nhead),
+                    cout4=pk.lin4_second(sd[p + "multihead_attn.out_proj.weight"], dh, nhead),
+                    ff14=pk.lin4_first(sd[p + "linear1.weight"], 1, 0, fs, nhead),
+                    ff24=pk.lin4_second(sd[p + "linear2.weight"], fs, nhead)))
+            else:
+                blocks.append({})
             L += 1
         if L == 0 or L > _lib.MMT_MAX_LAYERS:
             raise MmtError(f"decoder with {L} layers is not supported (1..{_lib.MMT_MAX_LAYERS})")
