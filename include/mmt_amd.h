@@ -154,9 +154,10 @@ typedef struct {
 /* short-sequence multi-head attention with explicit (batch stride, row stride) per operand, in floats */
 typedef struct {
   const float *q, *k, *v;
-  float *o, *probs;                 /* probs (B,H,Lq,Lk) stash, zero for masked keys */
+  float *o, *probs;                 /* probs stash, zero for masked keys: row (b,h,i) at (b*H+h)*p_hs + i*p_rs, Lk floats */
   const uint8_t *pad;               /* (B,Lk) key padding or NULL */
   int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+  int64_t p_hs, p_rs;               /* probs strides; contiguous (B,H,Lq,Lk) is p_hs = Lq*Lk, p_rs = Lk */
   int32_t B, H, Lq, Lk, dh, causal, causal_offset;
   float scale;
 } mmt_attn_args;

@@ -89,7 +89,7 @@ class GemmArgs(C.Structure):
 
 class AttnArgs(C.Structure):
     _fields_ = [("q", fptr), ("k", fptr), ("v", fptr), ("o", fptr), ("probs", fptr), ("pad", fptr)] + \
-               [(n, C.c_int64) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs")] + \
+               [(n, C.c_int64) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs", "p_hs", "p_rs")] + \
                [(n, C.c_int32) for n in ("B", "H", "Lq", "Lk", "dh", "causal", "causal_offset")] + [("scale", C.c_float)]
 
 

@@ -127,7 +127,7 @@ def _bld(t, name, B, L, d):
     return t.stride(0), t.stride(1)
 
 
-def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None):
+def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None, probs_strides=None):
     B, Lq, d = q.shape
     Lk = k.shape[1]
     a = _lib.AttnArgs()
@@ -139,8 +139,14 @@ def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None)
         a.o_bs, a.o_rs = _bld(o, "o", B, Lq, d)
         a.o = o.data_ptr()
     _dev(probs, "probs")
-    if not probs.is_contiguous() or probs.numel() != B * nhead * Lq * Lk:
-        raise MmtError(f"probs: expected {B * nhead * Lq * Lk} contiguous floats")
+    if probs_strides is None:
+        if not probs.is_contiguous() or probs.numel() != B * nhead * Lq * Lk:
+            raise MmtError(f"probs: expected {B * nhead * Lq * Lk} contiguous floats")
+        a.p_hs, a.p_rs = Lq * Lk, Lk
+    else:       # rows of a larger stash: (b,h,i) at probs[(b*H+h)*p_hs + i*p_rs : +Lk]
+        a.p_hs, a.p_rs = int(probs_strides[0]), int(probs_strides[1])
+        if not probs.is_contiguous() or probs.numel() < (B * nhead - 1) * a.p_hs + (Lq - 1) * a.p_rs + Lk:
+            raise MmtError("probs: the strided stash is smaller than the rows addressed")
     a.probs = probs.data_ptr()
     if pad is not None:
         _dev(pad, "pad", torch.uint8)
@@ -162,9 +168,11 @@ def attention_fwd(q, k, v, o, probs, nhead, scale, pad=None, causal=False, causa
     _lib.check(lib.mmt_attention_fwd(C.byref(a), _stream()), "mmt_attention_fwd")
 
 
-def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale):
-    """dq (=), dk (+=), dv (+=) from d_o and the stashed probabilities; dk and dv must share strides."""
-    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale)
+def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale, probs_strides=None):
+    """dq (=), dk (+=), dv (+=) from d_o and the stashed probabilities; dk and dv must share strides.
+    ``probs_strides`` = (stride between (b,h) slabs, stride between query rows) when ``probs`` starts inside a
+    larger (B,H,Lq',Lk') stash."""
+    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale, probs_strides=probs_strides)
     B, Lq, d = q.shape
     Lk = k.shape[1]
     do_bs, do_rs = _bld(d_o, "d_o", B, Lq, d)

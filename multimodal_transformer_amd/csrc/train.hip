@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void mmt_attn_fwd_kernel(mmt_attn_args a) {
   p0 *= inv;
   p1 *= inv;
   if (live) {
-    float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
+    float *P = a.probs + (size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs;
     if (l16 < a.Lk) P[l16] = p0;
     if (l16 + 16 < a.Lk) P[l16 + 16] = p1;
   }
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
   float *dK = dk + (size_t)b * dk_bs + h * DH + l16 * DPL, *dV = dv + (size_t)b * dk_bs + h * DH + l16 * DPL;
   const int Lk = live ? a.Lk : 0;
   for (int i = 0; i < a.Lq; ++i) {
-    const float *P = a.probs + ((size_t)(b * a.H + h) * a.Lq + i) * a.Lk;
+    const float *P = a.probs + (size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs;
     const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * DH;
     const float *g = dO + (size_t)b * do_bs + (size_t)i * do_rs + h * DH;
     f32x4 gv[NQ];
@@ -631,6 +631,8 @@ static int check_attn(const mmt_attn_args *a, const char *who) {
   if (!a || !a->q || !a->k || !a->v || !a->probs) return mmt_set_error(MMT_EINVAL, "%s: null pointer", who);
   if (a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0 || a->Lk > 32 || (a->dh != 16 && a->dh != 32 && a->dh != 64))
     return mmt_set_error(MMT_EINVAL, "%s: need B,H,Lq > 0, 1 <= Lk <= 32, head dim 16, 32 or 64", who);
+  if (a->p_rs < a->Lk || a->p_hs < (int64_t)(a->Lq - 1) * a->p_rs + a->Lk)
+    return mmt_set_error(MMT_EINVAL, "%s: probs strides overlap (need p_rs >= Lk, p_hs >= (Lq-1)*p_rs + Lk)", who);
   if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v) & 15 || (a->q_bs | a->q_rs | a->k_bs | a->k_rs | a->v_bs | a->v_rs) & 3)
     return mmt_set_error(MMT_EINVAL, "%s: q/k/v head slices must be 16-byte aligned (strides multiples of 4 floats)", who);
   return MMT_OK;

@@ -115,8 +115,13 @@ class _Packer:
         return holder
 
     def finish(self):
+        self.arena.alloc()
+        return self.run()
+
+    def run(self):
+        """(Re)fill the arena from the source tensors: every job reads its source where it lives now, so after an
+        in-place parameter update this refreshes the packed copies without allocating (HIP-graph capturable)."""
         A = self.arena
-        A.alloc()
         st = _stream()
         for job in self.jobs:
             if job[0] == "lin":
@@ -281,6 +286,7 @@ class PackedDecoder:
             else:
                 memf = _mlp_desc(pk, mem_fusion_sd, "")
         self.arena = pk.finish()
+        self._packer = pk
         _copy_struct(D.input_fc, lin_in)
         _copy_struct(D.output_fc, lin_out)
         D.pe = pe[0]
@@ -300,6 +306,11 @@ class PackedDecoder:
         self.has_head = head is not None
         self.desc = D
         self.d_model, self.n_in, self.n_out = d, n_in, D.n_out
+
+
+    def repack(self):
+        """Refresh the packed copies from the parameter tensors this descriptor was built from (same addresses)."""
+        self._packer.run()
 
 
 class PackedCnn:
@@ -473,8 +484,9 @@ def _workspace(nfloats, device):
 
 
 def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12, map_feat=None, mem_feat=None,
-                    tgt=None, want_h=False):
-    """Autoregressive (tgt=None) or teacher-forced decode.  Returns (pred_st (B,ph,n_in) | None, h (B,ph,n_out) | None)."""
+                    tgt=None, want_h=False, pred_out=None):
+    """Autoregressive (tgt=None) or teacher-forced decode.  Returns (pred_st (B,ph,n_in) | None, h (B,ph,n_out) | None).
+    ``pred_out``: caller-owned (B,ph,n_in) buffer for the autoregressive result (no allocation in this call)."""
     _chk(memory, "memory", (None, None, dec.d_model))
     B, T, _ = memory.shape
     if pad_mask is not None:
@@ -494,7 +506,13 @@ def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12,
         _chk(mem_feat, "mem_feat", (B, None))
         mf = mem_feat.shape[1]
     dev = memory.device
-    pred = torch.empty(B, ph, dec.n_in, dtype=torch.float32, device=dev) if tgt is None else None
+    pred = None
+    if tgt is None:
+        if pred_out is not None:
+            _chk(pred_out, "pred_out", (B, ph, dec.n_in))
+            pred = pred_out
+        else:
+            pred = torch.empty(B, ph, dec.n_in, dtype=torch.float32, device=dev)
     h = torch.empty(B, ph, dec.n_out, dtype=torch.float32, device=dev) if (want_h or tgt is not None) else None
     lib = _lib.load()
     ws = _workspace(lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph), dev)

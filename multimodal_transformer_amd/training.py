@@ -24,6 +24,7 @@ import math
 import torch
 
 from . import _train_kernels as K
+from . import ops
 from ._lib import MmtError
 
 
@@ -76,6 +77,7 @@ class TrainEngine:
         self.head_out = self.head.layer_seq.out_mlp
         if not isinstance(self.head_out, torch.nn.Linear):
             raise MmtError("decoder head must be a regression-mode Mlp")
+        self._pdec = None
         self._collect_params(model)
         self._alloc()
 
@@ -127,7 +129,7 @@ class TrainEngine:
         # encoder
         S.x0, S.pad = b(Re, self.n_in), b(B, T, dtype=torch.uint8)
         S.pe_enc = self.enc.pos_encoder.pe[:T].to(self.device).repeat(B, 1).contiguous()
-        S.pe_dec = self.dec.pos_encoder.pe[:ph].to(self.device).contiguous()
+        S.pe_dec = self.dec.pos_encoder.pe[:ph].to(self.device).repeat_interleave(B, dim=0).contiguous()   # row s*B+b
         fe, fd = self.f_enc, self.f_dec
         S.eh = [b(Re, d) for _ in range(self.Le + 1)]
         S.eqkv = [b(Re, 3 * d) for _ in range(self.Le)]
@@ -148,21 +150,23 @@ class TrainEngine:
         S.tok = b(ph, B, self.n_pos) if self.teacher_forced else S.pos[:ph]      # decoder input tokens, step-major
         S.x = [b(ph, B, d) for _ in range(L + 1)]
         S.qkv = [b(ph, B, 3 * d) for _ in range(L)]
-        S.p1 = [b(ph, B * H * ph) for _ in range(L)]
-        S.p2 = [b(ph, B * H * T) for _ in range(L)]
+        S.p1 = [b(B * H * ph * ph) for _ in range(L)]      # (B,H,ph,ph) causal self-attention probabilities
+        S.p2 = [b(B * H * ph * T) for _ in range(L)]       # (B,H,ph,T)
         for n in ("a1", "x1", "cq", "a2", "x2", "xhat1", "xhat2", "xhat3"):
             setattr(S, n, [b(ph, B, d) for _ in range(L)])
         for n in ("rstd1", "rstd2", "rstd3"):
             setattr(S, n, [b(ph, B) for _ in range(L)])
         S.f1 = [b(ph, B, fd) for _ in range(L)]
         S.mkv = [b(Re, 2 * d) for _ in range(L)]
-        S.tmp = b(B, d)
+        S.tmp = b(ph * B, d)
         no, nh = self.n_out, len(self.head_hidden)
         S.ho = b(ph, B, no)
         S.hu = [b(ph, B, no) for _ in range(nh)]
         S.hxhat = [b(ph, B, no) for _ in range(nh)]
         S.hrstd = [b(ph, B) for _ in range(nh)]
-        S.htmp = b(B, no)
+        S.htmp = b(ph * B, no)
+        S.delta = b(ph, B, self.n_pos)
+        S.pred = b(B, ph, self.n_pos)                      # autoregressive decode, agent-major (kernel output)
         # decoder gradients, step-major (kept for the deferred weight-gradient GEMMs)
         S.G = b(ph + 1, B, self.n_pos)
         S.gx = [b(ph, B, d) for _ in range(L + 1)]
@@ -214,40 +218,70 @@ class TrainEngine:
                 S.tok[1:].copy_(self.y_st[:, :ph - 1].permute(1, 0, 2))
         else:
             S.pos[0].copy_(self.x_st[:, -1, 0:self.n_pos])      # start token = standardised current position
-        for s in range(ph):
-            K.gemm(S.tok[s], _t(dec.input_fc.weight), S.x[0][s], bias=dec.input_fc.bias,
-                   addend=S.pe_dec[s:s + 1].expand(B, d))
-            for l, lay in enumerate(layers):
-                sa, ca = lay.self_attn, lay.multihead_attn
-                x = S.x[l][s]
-                K.gemm(x, _t(sa.in_proj_weight), S.qkv[l][s], bias=sa.in_proj_bias)
-                c = S.qkv[l]
-                K.attention_fwd(c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
-                                c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.a1[l][s:s + 1].permute(1, 0, 2),
-                                S.p1[l][s][:B * H * (s + 1)], H, self.scale)
-                K.gemm(S.a1[l][s], _t(sa.out_proj.weight), S.tmp, bias=sa.out_proj.bias, addend=x)
-                K.layernorm_fwd(S.tmp, None, lay.norm1.weight, lay.norm1.bias, S.x1[l][s], S.xhat1[l][s], S.rstd1[l][s])
-                K.gemm(S.x1[l][s], _t(ca.in_proj_weight[:d]), S.cq[l][s], bias=ca.in_proj_bias[:d])
-                mkv = S.mkv[l].view(B, T, 2 * d)
-                K.attention_fwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:],
-                                S.a2[l][s:s + 1].permute(1, 0, 2), S.p2[l][s], H, self.scale, pad=S.pad)
-                K.gemm(S.a2[l][s], _t(ca.out_proj.weight), S.tmp, bias=ca.out_proj.bias, addend=S.x1[l][s])
-                K.layernorm_fwd(S.tmp, None, lay.norm2.weight, lay.norm2.bias, S.x2[l][s], S.xhat2[l][s], S.rstd2[l][s])
-                K.gemm(S.x2[l][s], _t(lay.linear1.weight), S.f1[l][s], bias=lay.linear1.bias, relu=True)
-                K.gemm(S.f1[l][s], _t(lay.linear2.weight), S.tmp, bias=lay.linear2.bias, addend=S.x2[l][s])
-                K.layernorm_fwd(S.tmp, None, lay.norm3.weight, lay.norm3.bias, S.x[l + 1][s], S.xhat3[l][s],
-                                S.rstd3[l][s])
-            K.gemm(S.x[self.Ld][s], _t(dec.output_fc.weight), S.ho[s], bias=dec.output_fc.bias)
-            z = S.ho[s]
-            for i, (lin, ln) in enumerate(self.head_hidden):
-                K.gemm(z, _t(lin.weight), S.htmp, bias=lin.bias)
-                K.layernorm_fwd(S.htmp, None, ln.weight, ln.bias, S.hu[i][s], S.hxhat[i][s], S.hrstd[i][s], relu=True)
-                z = S.hu[i][s]
-            K.gemm(z, _t(self.head_out.weight), S.pos[s + 1], bias=self.head_out.bias, addend=S.pos[s])
+        if not self.teacher_forced:
+            # The autoregressive decode itself runs on the fused decoder kernels (positions only, nothing kept); with the
+            # tokens known, every activation the backward needs is recomputed for all ph steps at once: causal
+            # self-attention over the steps equals the KV-cached recurrence, and ph*B-row GEMMs replace ph B-row ones.
+            self._ar_decode()
+        self._decoder_all_steps()
+        if self.teacher_forced:     # positions = running sum of the head outputs (mgcvae.py:352,370), from pos[0] = 0
+            R = ph * B
+            z = (S.hu[-1] if self.head_hidden else S.ho).view(R, self.n_out)
+            K.gemm(z, _t(self.head_out.weight), S.delta.view(R, self.n_pos), bias=self.head_out.bias)
+            K.cumsum_axis(S.delta.view(1, ph, B * self.n_pos), S.pos[1:].view(1, ph, B * self.n_pos), 1)
         # loss value and dL/dpos in one pass (mgcvae.py:614-620)
         self.loss.zero_()
         K.l2_loss_bwd(S.pos[1:], self.y_st, S.G[1:], self.loss)
         return self.loss
+
+    def _decoder_all_steps(self):
+        """Decoder stack + head hidden layers for all ph steps at once on the tokens in ``S.tok`` (step-major rows
+        s*B+b), keeping every activation the backward reads.  Needs the encoder stash and ``S.mkv``."""
+        S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
+        dec = self.dec
+        layers = dec.transformer_decoder.layers
+        R = ph * B
+        f2 = lambda t: t.view(R, t.shape[-1])
+        K.gemm(f2(S.tok), _t(dec.input_fc.weight), f2(S.x[0]), bias=dec.input_fc.bias, addend=S.pe_dec)
+        mask_b = S.pad
+        for l, lay in enumerate(layers):
+            sa, ca = lay.self_attn, lay.multihead_attn
+            K.gemm(f2(S.x[l]), _t(sa.in_proj_weight), f2(S.qkv[l]), bias=sa.in_proj_bias)
+            c = S.qkv[l].permute(1, 0, 2)                  # (B,ph,3d) view of the step-major stash
+            K.attention_fwd(c[:, :, 0:d], c[:, :, d:2 * d], c[:, :, 2 * d:], S.a1[l].permute(1, 0, 2), S.p1[l], H,
+                            self.scale, causal=True)
+            K.gemm(f2(S.a1[l]), _t(sa.out_proj.weight), S.tmp, bias=sa.out_proj.bias, addend=f2(S.x[l]))
+            K.layernorm_fwd(S.tmp, None, lay.norm1.weight, lay.norm1.bias, f2(S.x1[l]), f2(S.xhat1[l]), S.rstd1[l].view(R))
+            K.gemm(f2(S.x1[l]), _t(ca.in_proj_weight[:d]), f2(S.cq[l]), bias=ca.in_proj_bias[:d])
+            mkv = S.mkv[l].view(B, T, 2 * d)
+            K.attention_fwd(S.cq[l].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.a2[l].permute(1, 0, 2), S.p2[l], H,
+                            self.scale, pad=mask_b)
+            K.gemm(f2(S.a2[l]), _t(ca.out_proj.weight), S.tmp, bias=ca.out_proj.bias, addend=f2(S.x1[l]))
+            K.layernorm_fwd(S.tmp, None, lay.norm2.weight, lay.norm2.bias, f2(S.x2[l]), f2(S.xhat2[l]), S.rstd2[l].view(R))
+            K.gemm(f2(S.x2[l]), _t(lay.linear1.weight), f2(S.f1[l]), bias=lay.linear1.bias, relu=True)
+            K.gemm(f2(S.f1[l]), _t(lay.linear2.weight), S.tmp, bias=lay.linear2.bias, addend=f2(S.x2[l]))
+            K.layernorm_fwd(S.tmp, None, lay.norm3.weight, lay.norm3.bias, f2(S.x[l + 1]), f2(S.xhat3[l]),
+                            S.rstd3[l].view(R))
+        K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), f2(S.ho), bias=dec.output_fc.bias)
+        z = f2(S.ho)
+        for i, (lin, ln) in enumerate(self.head_hidden):
+            K.gemm(z, _t(lin.weight), S.htmp, bias=lin.bias)
+            K.layernorm_fwd(S.htmp, None, ln.weight, ln.bias, f2(S.hu[i]), f2(S.hxhat[i]), S.hrstd[i].view(R), relu=True)
+            z = f2(S.hu[i])
+
+    def _ar_decode(self):
+        """pos[1:] <- the 12-step autoregressive decode of the current parameters (mgcvae.py:375-449) on the fused
+        decoder kernels, from the encoder output and start token already in the stash."""
+        S = self.s
+        if self._pdec is None:      # packed copies alias the parameters: built once, refreshed in place every step
+            def dev_sd(m):
+                return {k: v.detach() for k, v in m.state_dict(keep_vars=True).items()}
+            self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head))
+        else:
+            self._pdec.repack()
+        ops.decoder_forward(self._pdec, S.eh[self.Le].view(self.B, self.T, self.d), S.pad, start_pos=S.pos[0], ph=self.ph,
+                            pred_out=S.pred)
+        S.pos[1:].copy_(S.pred.permute(1, 0, 2))
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dY, X, w, bias=None):
@@ -294,18 +328,18 @@ class TrainEngine:
                 K.layernorm_bwd(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s])
                 K.gemm(S.go2[l][s], ca.out_proj.weight, S.ga2[l][s])
                 mkv, gmkv = S.mkv[l].view(B, T, 2 * d), S.gmkv[l].view(B, T, 2 * d)
-                K.attention_bwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s],
+                K.attention_bwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s * T:],
                                 S.ga2[l][s:s + 1].permute(1, 0, 2), S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d],
-                                gmkv[:, :, d:], H, self.scale)
+                                gmkv[:, :, d:], H, self.scale, probs_strides=(ph * T, T))
                 K.gemm(S.gcq[l][s], ca.in_proj_weight[:d], S.gx1[l][s], addend=S.go2[l][s])
                 K.layernorm_bwd(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s])
                 K.gemm(S.go1[l][s], sa.out_proj.weight, S.ga1[l][s])
                 c, gc = S.qkv[l], S.gqkv[l]
                 K.attention_bwd(c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
-                                c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s][:B * H * (s + 1)],
+                                c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s * ph:],
                                 S.ga1[l][s:s + 1].permute(1, 0, 2), gc[s:s + 1, :, 0:d].permute(1, 0, 2),
                                 gc[0:s + 1, :, d:2 * d].permute(1, 0, 2), gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), H,
-                                self.scale)
+                                self.scale, probs_strides=(ph * ph, ph))
                 K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s])
             if s > 0 and self.teacher_forced:      # G[s] = dL/dpos[s] + residual (cumsum) path; tokens are constants
                 K.add_inplace(S.G[s], S.G[s + 1])

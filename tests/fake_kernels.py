@@ -94,10 +94,14 @@ def attention_fwd(q, k, v, o, probs, nhead, scale, pad=None, causal=False, causa
     o.copy_(out.to(o.dtype))
 
 
-def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale):
+def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale, probs_strides=None):
     B, Lq, d = q.shape
     Lk = k.shape[1]
-    p = probs.double().view(B, nhead, Lq, Lk)
+    if probs_strides is None:
+        p = probs.double().view(B, nhead, Lq, Lk)
+    else:
+        hs, rs = probs_strides
+        p = torch.as_strided(probs, (B, nhead, Lq, Lk), (nhead * hs, hs, rs, 1)).double()
     g = _heads(d_o, nhead)
     dp = g @ _heads(v, nhead).transpose(-1, -2)
     ds = p * (dp - (p * dp).sum(-1, keepdim=True)) * scale
@@ -158,13 +162,31 @@ def add_inplace(y, x):
     y.add_(x)
 
 
+def ar_decode(eng):
+    """Stand-in for TrainEngine._ar_decode (the fused HIP decoder): the same autoregressive recurrence, obtained by
+    running the engine's own all-steps pass once per step with the teacher-forced wiring (causal attention makes step s
+    independent of the tokens after it) and feeding position s+1 = position s + head output back as the next token."""
+    S, ph = eng.s, eng.ph
+    dec, f2 = eng.dec, (lambda t: t.view(ph * eng.B, t.shape[-1]))
+    for s in range(ph):
+        eng._decoder_all_steps()
+        z = f2(S.hu[-1]) if eng.head_hidden else f2(S.ho)
+        gemm(z, eng.head_out.weight.t(), f2(S.delta), bias=eng.head_out.bias)
+        S.pos[s + 1].copy_(S.pos[s] + S.delta[s])
+
+
 ALL = ("softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
        "history_prepare", "adamw_table", "adamw_step", "lr_step")
 
 
-def install(monkeypatch):
+def install(monkeypatch=None):
+    """Patch the kernel wrappers (and the engine's fused-decoder call) with the stand-ins; without a monkeypatch
+    fixture (spawned worker processes) the patch is permanent for the process."""
     import sys
     from multimodal_transformer_amd import _train_kernels as K
+    from multimodal_transformer_amd.training import TrainEngine
     me = sys.modules[__name__]
+    put = monkeypatch.setattr if monkeypatch is not None else setattr
     for n in ALL:
-        monkeypatch.setattr(K, n, torch.no_grad()(getattr(me, n)))   # the real kernels never build autograd graphs
+        put(K, n, torch.no_grad()(getattr(me, n)))   # the real kernels never build autograd graphs
+    put(TrainEngine, "_ar_decode", torch.no_grad()(ar_decode))

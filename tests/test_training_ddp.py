@@ -20,8 +20,7 @@ def _worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     import fake_kernels
     from multimodal_transformer_amd import _train_kernels as K, training
-    for n in fake_kernels.ALL:
-        setattr(K, n, torch.no_grad()(getattr(fake_kernels, n)))
+    fake_kernels.install()
     from helpers import TINY_TR
     from multimodal_transformer_amd.config import make_hyperparams
     from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
