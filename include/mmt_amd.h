@@ -149,6 +149,12 @@ typedef struct {
   const float *mask;
   int64_t ld_mask;
   int32_t relu, accumulate;
+  /* optional LayerNorm backward on the A operand (nn.LayerNorm over its K columns, A unit-stride in k, M <= 256):
+   * A'[m][k] = rstd[m] * (A[m][k] g[k] - mean_k(A g) - xhat[m][k] mean_k(A g xhat)) is what gets multiplied, and is
+   * also written to ln_dx (row stride ld_ln, like ln_xhat) when ln_dx != NULL.  ln_xhat == NULL: plain A. */
+  const float *ln_xhat, *ln_rstd, *ln_g;
+  float *ln_dx;
+  int64_t ld_ln;
 } mmt_gemm_args;
 
 /* short-sequence multi-head attention with explicit (batch stride, row stride) per operand, in floats */

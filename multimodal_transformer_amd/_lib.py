@@ -84,7 +84,8 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", fptr), ("sam", C.c_int64), ("sak", C.c_int64), ("B", fptr), ("sbk", C.c_int64),
                 ("sbn", C.c_int64), ("C", fptr), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("bias", fptr), ("addend", fptr), ("ld_add", C.c_int64), ("mask", fptr),
-                ("ld_mask", C.c_int64), ("relu", C.c_int32), ("accumulate", C.c_int32)]
+                ("ld_mask", C.c_int64), ("relu", C.c_int32), ("accumulate", C.c_int32), ("ln_xhat", fptr),
+                ("ln_rstd", fptr), ("ln_g", fptr), ("ln_dx", fptr), ("ld_ln", C.c_int64)]
 
 
 class AttnArgs(C.Structure):

@@ -39,9 +39,11 @@ def _rows(t, name):
     return t.stride(0)
 
 
-def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False):
-    """Cm (+)= epi(A @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
-    epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0."""
+def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None):
+    """Cm (+)= epi(A' @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
+    epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0.
+    ``ln_bwd=(xhat, rstd, g, dx)``: A is the gradient at a LayerNorm output and A' = its LayerNorm backward (the
+    input gradient, also stored to ``dx``), fused into the operand load; without it A' = A."""
     _dev(A, "A"), _dev(B, "B")
     M, K = A.shape
     K2, N = B.shape
@@ -66,6 +68,15 @@ def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=Fal
             raise MmtError(f"gemm: mask shape {tuple(mask.shape)} != {(M, N)}")
         g.mask, g.ld_mask = mask.data_ptr(), _rows(mask, "mask")
     g.relu, g.accumulate = int(bool(relu)), int(bool(accumulate))
+    if ln_bwd is not None:
+        xhat, rstd, gamma, dx = ln_bwd
+        _dev(xhat, "xhat"), _dev(rstd, "rstd"), _dev(gamma, "ln weight"), _dev(dx, "dx")
+        if tuple(xhat.shape) != (M, K) or tuple(dx.shape) != (M, K) or _rows(xhat, "xhat") != _rows(dx, "dx"):
+            raise MmtError("gemm: ln_bwd xhat / dx must be (M,K) with equal row strides")
+        if rstd.numel() != M or not rstd.is_contiguous() or gamma.numel() != K or not gamma.is_contiguous():
+            raise MmtError("gemm: ln_bwd rstd (M) / weight (K) must be contiguous vectors")
+        g.ln_xhat, g.ln_rstd, g.ln_g, g.ln_dx, g.ld_ln = xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), \
+            dx.data_ptr(), _rows(xhat, "xhat")
     lib = _lib.load()
     _lib.check(lib.mmt_gemm(C.byref(g), _stream()), "mmt_gemm")
 

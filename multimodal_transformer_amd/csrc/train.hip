@@ -151,6 +151,139 @@ void launch_panel(const mmt_gemm_args &g, hipStream_t st) {
   hipLaunchKernelGGL((mmt_gemm_panel_kernel<BT, AK, BK>), dim3((g.N + BT - 1) / BT, (g.M + BT - 1) / BT), dim3(256), lds, st, g);
 }
 
+// ------------------------------------------------------------------------------------------ row-block GEMM (small M)
+// The backward sweep is a chain of ~70 dependent GEMMs per decoder step with M = B rows: latency, not throughput.  A
+// workgroup owns a 16 x 32 output tile and the WHOLE K range (K <= 768): every global load of the kernel is requested
+// in one burst straight into MFMA operand layout (no LDS staging), the K range is dealt over the 4 waves in 16-wide
+// chunks (chunk c -> wave c % 4) and the 4 partial tiles are summed through LDS in wave order.  M/16 x N/32
+// workgroups: 4x the panel kernel's at the same shape.
+// LN = true: the A operand is the gradient at a LayerNorm output; its LayerNorm backward (row statistics over the K
+// columns: the workgroup holds whole rows) is applied in registers before the multiply, and the workgroups of the
+// first column block also store it (ln_dx) for the residual path and the deferred weight-gradient GEMMs.
+template <int NCH, bool BK, bool LN>
+__global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g) {
+  __shared__ float red[4][2][16 * 17];
+  __shared__ float stat[4][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32, nch = g.K >> 4;
+  const int m = m0 + l15;
+  const bool mok = m < g.M;
+  const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
+  f32x4 a[NCH], b[2][NCH];
+  f32x4 xh[LN ? NCH : 1], gg[LN ? NCH : 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = 4 * i + w, kk = 16 * c + 4 * kq;
+    const bool cok = c < nch;
+    a[i] = bl4(ra, (cok && mok) ? (unsigned)(m * (int)g.sam + kk) * 4u : OOB);
+    if constexpr (LN) {
+      xh[i] = bl4(mk_rsrc(g.ln_xhat), (cok && mok) ? (unsigned)(m * (int)g.ld_ln + kk) * 4u : OOB);
+      gg[i] = bl4(mk_rsrc(g.ln_g), cok ? (unsigned)kk * 4u : OOB);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = n0 + 16 * t + l15;
+      const bool ok = cok && n < g.N;
+      if constexpr (BK) {
+        b[t][i] = bl4(rb, ok ? (unsigned)(n * (int)g.sbn + kk) * 4u : OOB);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[t][i][e] = bl1(rb, ok ? (unsigned)((kk + e) * (int)g.sbk + n) * 4u : OOB);
+      }
+    }
+  }
+  if constexpr (LN) {
+    const float rstd = mok ? g.ln_rstd[m] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dg = a[i][e] * gg[i][e];
+        a[i][e] = dg;
+        s1 += dg;
+        s2 = fmaf(dg, xh[i][e], s2);
+      }
+    s1 = xor32_sum(xor16_sum(s1));           // over the four k sub-columns of the row inside this wave
+    s2 = xor32_sum(xor16_sum(s2));
+    if (kq == 0) {
+      stat[w][l15][0] = s1;
+      stat[w][l15][1] = s2;
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)g.K;
+    const float m1 = (((stat[0][l15][0] + stat[1][l15][0]) + stat[2][l15][0]) + stat[3][l15][0]) * inv;
+    const float m2 = (((stat[0][l15][1] + stat[1][l15][1]) + stat[2][l15][1]) + stat[3][l15][1]) * inv;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[i][e] = rstd * (a[i][e] - m1 - xh[i][e] * m2);
+      const int c = 4 * i + w;
+      if (blockIdx.x == 0 && g.ln_dx && c < nch && mok)
+        *reinterpret_cast<f32x4 *>(g.ln_dx + (size_t)m * g.ld_ln + 16 * c + 4 * kq) = a[i];
+    }
+  }
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    if (4 * i + w < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[t][i][e], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][t][(4 * kq + r) * 17 + l15] = acc[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int o = tid + 256 * it, t = o >> 8, row = (o & 255) >> 4, col = o & 15;
+    const int mm = m0 + row, n = n0 + 16 * t + col;
+    if (mm >= g.M || n >= g.N) continue;
+    const int ix = row * 17 + col;
+    float v = ((red[0][t][ix] + red[1][t][ix]) + red[2][t][ix]) + red[3][t][ix];
+    if (g.bias) v += g.bias[n];
+    if (g.addend) v += g.addend[(size_t)mm * g.ld_add + n];
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.mask && !(g.mask[(size_t)mm * g.ld_mask + n] > 0.f)) v = 0.f;
+    float *cp = g.C + (size_t)mm * g.ldc + n;
+    *cp = g.accumulate ? (*cp + v) : v;
+  }
+}
+
+template <bool BK, bool LN>
+void launch_rows(const mmt_gemm_args &g, hipStream_t st) {
+  const dim3 grid((g.N + 31) / 32, (g.M + 15) / 16), blk(256);
+  if (g.K <= 256) hipLaunchKernelGGL((mmt_gemm_rows_kernel<4, BK, LN>), grid, blk, 0, st, g);
+  else if (g.K <= 512) hipLaunchKernelGGL((mmt_gemm_rows_kernel<8, BK, LN>), grid, blk, 0, st, g);
+  else hipLaunchKernelGGL((mmt_gemm_rows_kernel<12, BK, LN>), grid, blk, 0, st, g);
+}
+
+// ------------------------------------------------------------------------------------------ thin GEMM
+// A handful of outputs (M*N <= 2048) of a long reduction (weight gradients of the 2-column linears: K = ph*B rows):
+// one wave per output element, lanes stride the K range, fixed-order wave sum.  Any strides.
+__global__ __launch_bounds__(256) void mmt_gemm_thin_kernel(mmt_gemm_args g) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= g.M * g.N) return;
+  const int m = o / g.N, n = o - m * g.N;
+  const float *A = g.A + (size_t)m * g.sam, *B = g.B + (size_t)n * g.sbn;
+  float s = 0.f;
+  for (int k = lane; k < g.K; k += 64) s = fmaf(A[(size_t)k * g.sak], B[(size_t)k * g.sbk], s);
+  s = wave64_sum(s);
+  if (lane == 0) {
+    float v = s;
+    if (g.bias) v += g.bias[n];
+    if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+    float *cp = g.C + (size_t)m * g.ldc + n;
+    *cp = g.accumulate ? (*cp + v) : v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ GEMM
 constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;   // LDS row stride 20 floats (16-B aligned rows)
 
@@ -590,12 +723,31 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   const bool aligned = (((uintptr_t)g->A | (uintptr_t)g->B) & 15) == 0 && g->K % 4 == 0;
   const double amax = (double)g->M * (double)(ak ? g->sam : 1) + (double)g->K * (double)(ak ? 1 : g->sak);
   const double bmax = (double)g->N * (double)(bk ? g->sbn : 1) + (double)g->K * (double)(bk ? 1 : g->sbk);
+  hipStream_t st = (hipStream_t)stream;
+  // row-block kernel: few rows, whole K per workgroup (the dependent chain of the backward sweep)
+  const bool rows_ok = aligned && ak && g->K % 16 == 0 && g->K <= 768 && g->M <= 256 && amax < 5e8 && bmax < 5e8 &&
+                       (bk || (g->sbn == 1));
+  if (g->ln_xhat) {
+    if (!rows_ok || !g->ln_rstd || !g->ln_g || g->ld_ln % 4 || ((uintptr_t)g->ln_xhat & 15) || ((uintptr_t)g->ln_dx & 15) ||
+        ((uintptr_t)g->ln_g & 15))
+      return mmt_set_error(MMT_EINVAL, "mmt_gemm: the fused LayerNorm backward needs M <= 256, K <= 768 a multiple of 16, "
+                                       "16-byte aligned rows");
+    bk ? launch_rows<true, true>(*g, st) : launch_rows<false, true>(*g, st);
+    return launch_ok("mmt_gemm");
+  }
+  if (rows_ok && g->N >= 32) {
+    bk ? launch_rows<true, false>(*g, st) : launch_rows<false, false>(*g, st);
+    return launch_ok("mmt_gemm");
+  }
   if (aligned && (ak || ar) && (bk || br) && !(ar && !ak && bk) && amax < 5e8 && bmax < 5e8) {
-    hipStream_t st = (hipStream_t)stream;
     const bool big = ((g->M + 63) / 64) * ((g->N + 63) / 64) >= 128;
     if (ak && bk) big ? launch_panel<64, true, true>(*g, st) : launch_panel<32, true, true>(*g, st);
     else if (ak) big ? launch_panel<64, true, false>(*g, st) : launch_panel<32, true, false>(*g, st);
     else big ? launch_panel<64, false, false>(*g, st) : launch_panel<32, false, false>(*g, st);
+    return launch_ok("mmt_gemm");
+  }
+  if ((long)g->M * g->N <= 2048 && g->K >= 256) {
+    hipLaunchKernelGGL(mmt_gemm_thin_kernel, dim3((g->M * g->N + 3) / 4), dim3(256), 0, st, *g);
     return launch_ok("mmt_gemm");
   }
   dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM);

@@ -298,6 +298,16 @@ class TrainEngine:
         K.colsum(dy, self.g(ln.weight), b=xhat)
         K.colsum(dy, self.g(ln.bias))
 
+    def _ln_gemm(self, dy, xhat, rstd, gamma, dx, w, out, **kw):
+        """dx = LayerNorm backward of dy; out = epi(dx @ w).  One kernel when the row-block GEMM takes the shape (the
+        per-step sweep at B <= 256), two otherwise."""
+        M, Kd = dy.shape
+        if M <= 256 and Kd % 16 == 0 and Kd <= 768:
+            K.gemm(dy, w, out, ln_bwd=(xhat, rstd, gamma, dx), **kw)
+        else:
+            K.layernorm_bwd(dy, xhat, rstd, gamma, dx)
+            K.gemm(dx, w, out, **kw)
+
     def backward(self):
         """Reverse-time sweep.  ``forward`` must have run; ``S.G[1:]`` holds dL/dpos from the loss kernel."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
@@ -322,18 +332,19 @@ class TrainEngine:
             for l in range(L - 1, -1, -1):
                 lay = layers[l]
                 sa, ca = lay.self_attn, lay.multihead_attn
-                K.layernorm_bwd(S.gx[l + 1][s], S.xhat3[l][s], S.rstd3[l][s], lay.norm3.weight, S.gf2[l][s])
-                K.gemm(S.gf2[l][s], lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s])
+                # (each LayerNorm backward rides in the operand load of the GEMM that consumes it)
+                self._ln_gemm(S.gx[l + 1][s], S.xhat3[l][s], S.rstd3[l][s], lay.norm3.weight, S.gf2[l][s],
+                              lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s])
                 K.gemm(S.gf1[l][s], lay.linear1.weight, S.gx2[l][s], addend=S.gf2[l][s])
-                K.layernorm_bwd(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s])
-                K.gemm(S.go2[l][s], ca.out_proj.weight, S.ga2[l][s])
+                self._ln_gemm(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s],
+                              ca.out_proj.weight, S.ga2[l][s])
                 mkv, gmkv = S.mkv[l].view(B, T, 2 * d), S.gmkv[l].view(B, T, 2 * d)
                 K.attention_bwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s * T:],
                                 S.ga2[l][s:s + 1].permute(1, 0, 2), S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d],
                                 gmkv[:, :, d:], H, self.scale, probs_strides=(ph * T, T))
                 K.gemm(S.gcq[l][s], ca.in_proj_weight[:d], S.gx1[l][s], addend=S.go2[l][s])
-                K.layernorm_bwd(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s])
-                K.gemm(S.go1[l][s], sa.out_proj.weight, S.ga1[l][s])
+                self._ln_gemm(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s],
+                              sa.out_proj.weight, S.ga1[l][s])
                 c, gc = S.qkv[l], S.gqkv[l]
                 K.attention_bwd(c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
                                 c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s * ph:],
