@@ -609,6 +609,94 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
   }
 }
 
+// Same contract for Lk <= 16 and head dim 16 / 32: everything a (batch, head) group reads more than once -- its K rows,
+// the dK / dV rows it accumulates into, the V row of "its" key -- is requested up front with predicated buffer loads
+// and lives in registers across the queries; the only memory traffic inside the query loop is q, dO and the
+// probabilities.  (The general kernel above walks the keys with a load -> update -> store chain per key: one memory
+// round trip each, ~10 us for 12 keys.)
+template <int DPL>
+__device__ __forceinline__ void ld_dpl(float (&dst)[DPL], rsrc_t r, unsigned off) {
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) dst[e] = bl1(r, off == OOB ? OOB : off + 4u * e);
+}
+template <int DH>
+__global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, const float *__restrict__ dO, long do_bs, long do_rs,
+                                                             float *__restrict__ dq, long dq_bs, long dq_rs,
+                                                             float *__restrict__ dk, float *__restrict__ dv, long dk_bs,
+                                                             long dk_rs) {
+  constexpr int NQ = DH / 4, DPL = DH / 16;
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l16 = threadIdx.x & 15;
+  const bool live = grp < a.B * a.H;
+  const int gq = live ? grp : 0;
+  const int h = gq % a.H, b = gq / a.H;
+  const int Lk = live ? a.Lk : 0;
+  // wave-uniform descriptors (a per-lane base would make every load a readfirstlane loop); the group's base goes into the offset
+  const rsrc_t rk = mk_rsrc(a.k), rv = mk_rsrc(a.v), rdk = mk_rsrc(dk), rdv = mk_rsrc(dv);
+  const unsigned kb = (unsigned)(b * (int)a.k_bs + h * DH + l16 * DPL), vb = (unsigned)(b * (int)a.v_bs + h * DH);
+  const unsigned db = (unsigned)(b * (int)dk_bs + h * DH + l16 * DPL);
+  float kr[16][DPL], dkr[16][DPL], dvr[16][DPL];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    ld_dpl<DPL>(kr[j], rk, j < Lk ? (kb + (unsigned)(j * (int)a.k_rs)) * 4u : OOB);
+    ld_dpl<DPL>(dkr[j], rdk, j < Lk ? (db + (unsigned)(j * (int)dk_rs)) * 4u : OOB);
+    ld_dpl<DPL>(dvr[j], rdv, j < Lk ? (db + (unsigned)(j * (int)dk_rs)) * 4u : OOB);
+  }
+  f32x4 vrow[NQ];                    // V row of key l16
+#pragma unroll
+  for (int c = 0; c < NQ; ++c) vrow[c] = bl4(rv, l16 < Lk ? (vb + (unsigned)(l16 * (int)a.v_rs + 4 * c)) * 4u : OOB);
+  float *dQ = dq + (size_t)b * dq_bs + h * DH + l16 * DPL;
+  for (int i = 0; i < a.Lq; ++i) {
+    const float *P = a.probs + (size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs;
+    const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * DH;
+    const float *g = dO + (size_t)b * do_bs + (size_t)i * do_rs + h * DH;
+    const float p = l16 < Lk ? P[l16] : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + 4 * c);
+      t = fmaf(gv[0], vrow[c][0], t);
+      t = fmaf(gv[1], vrow[c][1], t);
+      t = fmaf(gv[2], vrow[c][2], t);
+      t = fmaf(gv[3], vrow[c][3], t);
+    }
+    const float dP = p > 0.f ? t : 0.f;
+    const float dot = row16_sum(p * dP);
+    const float ds = p * (dP - dot) * a.scale;
+    float qd[DPL], gd[DPL], dqa[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+      qd[e] = q[l16 * DPL + e];
+      gd[e] = g[l16 * DPL + e];
+      dqa[e] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {       // masked / absent keys carry p = ds = 0: the updates are exact no-ops
+      const float pj = __shfl(p, j, 16), dsj = __shfl(ds, j, 16);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) {
+        dqa[e] = fmaf(dsj, kr[j][e], dqa[e]);
+        dkr[j][e] = fmaf(dsj, qd[e], dkr[j][e]);
+        dvr[j][e] = fmaf(pj, gd[e], dvr[j][e]);
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) dQ[(size_t)i * dq_rs + e] = dqa[e];
+    }
+  }
+  float *dK = dk + (size_t)b * dk_bs + h * DH + l16 * DPL, *dV = dv + (size_t)b * dk_bs + h * DH + l16 * DPL;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < Lk) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) {
+        dK[(size_t)j * dk_rs + e] = dkr[j][e];
+        dV[(size_t)j * dk_rs + e] = dvr[j][e];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ loss / optimizer
 // dpos[t][b][:] = (pos - y) / ||pos - y|| / (B * ph)   with pos laid out [ph][B][2], y laid out [B][ph][2]
 __global__ void mmt_l2_loss_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ y, int B, int ph,
@@ -811,8 +899,17 @@ extern "C" int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long 
   const int total = a->B * a->H;                         // groups of 16 lanes
   const dim3 grid((total + 15) / 16), blk(256);
   hipStream_t st = (hipStream_t)stream;
-#define BWD(DHV) hipLaunchKernelGGL(mmt_attn_bwd_kernel<DHV>, grid, blk, 0, st, *a, d_o, do_bs, do_rs, dq, dq_bs, dq_rs, dk, dv, dk_bs, dk_rs)
-  if (a->dh == 16) BWD(16); else if (a->dh == 32) BWD(32); else BWD(64);
+#define BWD(KERNEL, DHV) hipLaunchKernelGGL(KERNEL<DHV>, grid, blk, 0, st, *a, d_o, do_bs, do_rs, dq, dq_bs, dq_rs, dk, dv, dk_bs, dk_rs)
+  // register-resident variant: few keys, 8-byte aligned per-lane slices, offsets within the buffer descriptors' range
+  const bool small = a->Lk <= 16 && a->dh <= 32 && ((uintptr_t)dk & 15) == 0 && ((uintptr_t)dv & 15) == 0 && (dk_bs & 3) == 0 &&
+                     (dk_rs & 3) == 0 &&
+                     (double)a->B * (double)std::max(std::max(a->k_bs, a->v_bs), (int64_t)dk_bs) +
+                             (double)a->Lk * (double)std::max(std::max(a->k_rs, a->v_rs), (int64_t)dk_rs) < 5e8;
+  if (small && a->dh == 16) BWD(mmt_attn_bwd16_kernel, 16);
+  else if (small) BWD(mmt_attn_bwd16_kernel, 32);
+  else if (a->dh == 16) BWD(mmt_attn_bwd_kernel, 16);
+  else if (a->dh == 32) BWD(mmt_attn_bwd_kernel, 32);
+  else BWD(mmt_attn_bwd_kernel, 64);
 #undef BWD
   return launch_ok("mmt_attention_bwd");
 }
