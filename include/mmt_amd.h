@@ -155,6 +155,13 @@ typedef struct {
   const float *ln_xhat, *ln_rstd, *ln_g;
   float *ln_dx;
   int64_t ld_ln;
+  /* optional split of the K range over `splitk` workgroup slices (weight gradients: K = ph*B rows, both operands with
+   * unit stride along their rows): slice z writes its partial product to C + z*part_stride (and asum + z*part_stride);
+   * the caller sums the slices.  asum != NULL: asum[m] = sum_k A[m][k] (the bias gradient) from the same pass.
+   * splitk <= 1 and asum == NULL: plain GEMM.  Not combined with bias/addend/relu/mask/accumulate. */
+  int32_t splitk, pad_;
+  int64_t part_stride;
+  float *asum;
 } mmt_gemm_args;
 
 /* short-sequence multi-head attention with explicit (batch stride, row stride) per operand, in floats */

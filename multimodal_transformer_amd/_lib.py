@@ -85,7 +85,8 @@ class GemmArgs(C.Structure):
                 ("sbn", C.c_int64), ("C", fptr), ("ldc", C.c_int64), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("bias", fptr), ("addend", fptr), ("ld_add", C.c_int64), ("mask", fptr),
                 ("ld_mask", C.c_int64), ("relu", C.c_int32), ("accumulate", C.c_int32), ("ln_xhat", fptr),
-                ("ln_rstd", fptr), ("ln_g", fptr), ("ln_dx", fptr), ("ld_ln", C.c_int64)]
+                ("ln_rstd", fptr), ("ln_g", fptr), ("ln_dx", fptr), ("ld_ln", C.c_int64), ("splitk", C.c_int32),
+                ("pad_", C.c_int32), ("part_stride", C.c_int64), ("asum", fptr)]
 
 
 class AttnArgs(C.Structure):

@@ -39,11 +39,14 @@ def _rows(t, name):
     return t.stride(0)
 
 
-def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None):
+def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1,
+         part_stride=0, asum=None):
     """Cm (+)= epi(A' @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
     epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0.
     ``ln_bwd=(xhat, rstd, g, dx)``: A is the gradient at a LayerNorm output and A' = its LayerNorm backward (the
-    input gradient, also stored to ``dx``), fused into the operand load; without it A' = A."""
+    input gradient, also stored to ``dx``), fused into the operand load; without it A' = A.
+    ``splitk`` > 1 (weight gradients): slice z of the K range writes its partial to ``Cm`` + z*``part_stride`` floats
+    (same for ``asum``), the caller sums the slices; ``asum`` (M) receives the row sums of A (the bias gradient)."""
     _dev(A, "A"), _dev(B, "B")
     M, K = A.shape
     K2, N = B.shape
@@ -77,6 +80,15 @@ def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=Fal
             raise MmtError("gemm: ln_bwd rstd (M) / weight (K) must be contiguous vectors")
         g.ln_xhat, g.ln_rstd, g.ln_g, g.ln_dx, g.ld_ln = xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), \
             dx.data_ptr(), _rows(xhat, "xhat")
+    if splitk > 1 or asum is not None:
+        if bias is not None or addend is not None or mask is not None or relu or accumulate or ln_bwd is not None:
+            raise MmtError("gemm: splitk / asum cannot be combined with an epilogue")
+        g.splitk, g.part_stride = int(splitk), int(part_stride)
+        if asum is not None:
+            _dev(asum, "asum")
+            if asum.numel() != M or not asum.is_contiguous():
+                raise MmtError("gemm: asum must be a contiguous vector of M elements")
+            g.asum = asum.data_ptr()
     lib = _lib.load()
     _lib.check(lib.mmt_gemm(C.byref(g), _stream()), "mmt_gemm")
 

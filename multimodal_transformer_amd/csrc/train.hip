@@ -32,7 +32,10 @@ namespace {
 // multiplied out of LDS, one barrier per panel.  An operand whose unit stride is K ("KC") sits in LDS as [row][k]
 // and feeds the MFMA with one ds_read_b128; one whose unit stride is the row index sits as [k][row] and feeds it
 // with four conflict-free ds_read_b32.  Covers X W^T (KC,KC), dY W (KC,rows) and dY^T X (rows,rows).
-template <int BT, bool AK, bool BK>
+// SPLIT (weight gradients, both operands row-major in the reduction dimension): blockIdx.z owns a 64-aligned slice of the
+// K range and writes its partial to C + z*part_stride; the workgroups of the first column block also reduce the row sums
+// of their A tile (asum: the bias gradient) from the registers the tile passes through anyway.
+template <int BT, bool AK, bool BK, bool SPLIT = false>
 __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
   constexpr int KC = 64, LDK = KC + 4, LDR = BT + 4;
   constexpr int ASZ = AK ? BT * LDK : KC * LDR, BSZ = BK ? BT * LDK : KC * LDR;
@@ -46,6 +49,15 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
   const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
   const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
   f32x4 ar[NI], br[NI];
+  int kbeg = 0, kend = g.K;
+  if constexpr (SPLIT) {
+    const int per = (((g.K + g.splitk - 1) / g.splitk) + KC - 1) / KC * KC;
+    kbeg = min(g.K, (int)blockIdx.z * per);
+    kend = min(g.K, kbeg + per);
+    g.C += (size_t)blockIdx.z * g.part_stride;
+  }
+  f32x4 rsum = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_sum = SPLIT && g.asum && blockIdx.x == 0;
   auto gload = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
@@ -54,14 +66,14 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
         ar[it] = bl4(ra, (gm < g.M && gk < g.K) ? (unsigned)(gm * (int)g.sam + gk) * 4u : OOB);
       } else {
         const int gk = k0 + tid / R4 + (256 / R4) * it, gm = m0 + 4 * (tid % R4);
-        ar[it] = bl4(ra, (gm < g.M && gk < g.K) ? (unsigned)(gk * (int)g.sak + gm) * 4u : OOB);
+        ar[it] = bl4(ra, (gm < g.M && gk < kend) ? (unsigned)(gk * (int)g.sak + gm) * 4u : OOB);
       }
       if (BK) {
         const int gn = n0 + (tid >> 4) + 16 * it, gk = k0 + 4 * (tid & 15);
         br[it] = bl4(rb, (gn < g.N && gk < g.K) ? (unsigned)(gn * (int)g.sbn + gk) * 4u : OOB);
       } else {
         const int gk = k0 + tid / R4 + (256 / R4) * it, gn = n0 + 4 * (tid % R4);
-        br[it] = bl4(rb, (gn < g.N && gk < g.K) ? (unsigned)(gk * (int)g.sbk + gn) * 4u : OOB);
+        br[it] = bl4(rb, (gn < g.N && gk < kend) ? (unsigned)(gk * (int)g.sbk + gn) * 4u : OOB);
       }
     }
   };
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
     for (int it = 0; it < NI; ++it) {
       if (AK) *reinterpret_cast<f32x4 *>(As + buf * ASZ + ((tid >> 4) + 16 * it) * LDK + 4 * (tid & 15)) = ar[it];
       else *reinterpret_cast<f32x4 *>(As + buf * ASZ + (tid / R4 + (256 / R4) * it) * LDR + 4 * (tid % R4)) = ar[it];
+      if constexpr (SPLIT && !AK) rsum += ar[it];       // out-of-range elements arrived as zeros
       if (BK) *reinterpret_cast<f32x4 *>(Bs + buf * BSZ + ((tid >> 4) + 16 * it) * LDK + 4 * (tid & 15)) = br[it];
       else *reinterpret_cast<f32x4 *>(Bs + buf * BSZ + (tid / R4 + (256 / R4) * it) * LDR + 4 * (tid % R4)) = br[it];
     }
@@ -79,14 +92,14 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
   for (int i = 0; i < WT; ++i)
 #pragma unroll
     for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int nc = (g.K + KC - 1) / KC;
-  gload(0);
+  const int nc = (kend - kbeg + KC - 1) / KC;
+  gload(kbeg);
   sstore(0);
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
-    if (c + 1 < nc) gload((c + 1) * KC);
+    if (c + 1 < nc) gload(kbeg + (c + 1) * KC);
     const float *A = As + (c & 1) * ASZ, *B = Bs + (c & 1) * BSZ;
-    const int kkmax = min(4, (g.K - c * KC + 15) >> 4);
+    const int kkmax = min(4, (kend - kbeg - c * KC + 15) >> 4);
     for (int kk = 0; kk < kkmax; ++kk) {
       float a[WT][4], b[WT][4];
 #pragma unroll
@@ -137,6 +150,19 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
         *cp = g.accumulate ? (*cp + v) : v;
       }
     }
+  if constexpr (SPLIT && !AK) {
+    if (do_sum) {      // thread (tid % R4) holds rows 4*(tid%R4)..+3 of the tile summed over its k rows: 256/R4 partials each
+      __syncthreads();
+      float *ps = smem;                         // [256 / R4][BT]
+      *reinterpret_cast<f32x4 *>(ps + (tid / R4) * BT + 4 * (tid % R4)) = rsum;
+      __syncthreads();
+      if (tid < BT && m0 + tid < g.M) {
+        float t = 0.f;
+        for (int r = 0; r < 256 / R4; ++r) t += ps[r * BT + tid];
+        g.asum[(size_t)blockIdx.z * g.part_stride + m0 + tid] = t;
+      }
+    }
+  }
 }
 
 template <int BT, bool AK, bool BK>
@@ -149,6 +175,18 @@ void launch_panel(const mmt_gemm_args &g, hipStream_t st) {
     attr = true;
   }
   hipLaunchKernelGGL((mmt_gemm_panel_kernel<BT, AK, BK>), dim3((g.N + BT - 1) / BT, (g.M + BT - 1) / BT), dim3(256), lds, st, g);
+}
+
+void launch_split(const mmt_gemm_args &g, hipStream_t st) {
+  constexpr int BT = 32, KC = 64, LDR = BT + 4;
+  constexpr size_t lds = 2 * (KC * LDR + KC * LDR) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)mmt_gemm_panel_kernel<BT, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((mmt_gemm_panel_kernel<BT, false, false, true>), dim3((g.N + BT - 1) / BT, (g.M + BT - 1) / BT, std::max(g.splitk, 1)),
+                     dim3(256), lds, st, g);
 }
 
 // ------------------------------------------------------------------------------------------ row-block GEMM (small M)
@@ -812,6 +850,14 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   const double amax = (double)g->M * (double)(ak ? g->sam : 1) + (double)g->K * (double)(ak ? 1 : g->sak);
   const double bmax = (double)g->N * (double)(bk ? g->sbn : 1) + (double)g->K * (double)(bk ? 1 : g->sbk);
   hipStream_t st = (hipStream_t)stream;
+  if (g->splitk > 1 || g->asum) {
+    if (!(aligned && ar && br && amax < 5e8 && bmax < 5e8) || g->bias || g->addend || g->mask || g->relu || g->accumulate ||
+        g->ln_xhat || g->splitk > 16 || (g->splitk > 1 && g->part_stride <= 0))
+      return mmt_set_error(MMT_EINVAL, "mmt_gemm: splitk / asum need A and B with unit stride along their rows (M, N "
+                                       "multiples of 4, 16-byte aligned), no epilogue, splitk <= 16");
+    launch_split(*g, st);
+    return launch_ok("mmt_gemm");
+  }
   // row-block kernel: few rows, whole K per workgroup (the dependent chain of the backward sweep)
   const bool rows_ok = aligned && ak && g->K % 16 == 0 && g->K <= 768 && g->M <= 256 && amax < 5e8 && bmax < 5e8 &&
                        (bk || (g->sbn == 1));

@@ -104,7 +104,12 @@ class TrainEngine:
                 raise MmtError("parameters must be contiguous fp32")
             offs.append(total)
             total += (p.numel() + 63) & ~63
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # [0] is the gradient bucket (what the all-reduce and the optimizer see); [1..SPLITK-1] receive the other K-slices of
+        # the split weight-gradient GEMMs at the same offsets and are summed into [0] at the end of backward()
+        self.SPLITK = 4
+        self.grad_total = total
+        self.flat_all = torch.zeros(self.SPLITK * total, dtype=torch.float32, device=self.device)
+        self.flat_grad = self.flat_all[:total]
         self.grad_of = {}
         self.grad_by_name = {}
         for (name, p), o in zip(named, offs):
@@ -286,13 +291,25 @@ class TrainEngine:
     # ------------------------------------------------------------------ backward
     def _wgrad(self, dY, X, w, bias=None):
         """gW = dY^T X over all rows, gb = column sums of dY."""
-        K.gemm(dY.t(), X, self.g(w))
-        if bias is not None:
-            K.colsum(dY, self.g(bias))
+        self._wgrad_rows(dY, X, self.g(w), self.g(bias) if bias is not None else None)
 
     def _wgrad_rows(self, dY, X, gw, gb):
+        R, M = dY.shape
+        N = X.shape[1]
+        if R >= 512 and M % 4 == 0 and N % 4 == 0 and M >= 32 and N >= 32 and dY.stride(1) == 1 and X.stride(1) == 1:
+            # one pass: K range split over SPLITK workgroup slices, bias gradient from the same operand tiles
+            K.gemm(dY.t(), X, gw, splitk=self.SPLITK, part_stride=self.grad_total, asum=gb)
+            self._split_used = True
+            return
         K.gemm(dY.t(), X, gw)
-        K.colsum(dY, gb)
+        if gb is not None:
+            K.colsum(dY, gb)
+
+    def _sum_split_parts(self):
+        if getattr(self, "_split_used", False):
+            t = self.grad_total
+            for z in range(1, self.SPLITK):
+                K.add_inplace(self.flat_grad, self.flat_all[z * t:(z + 1) * t])
 
     def _ln_grad(self, dy, xhat, ln):
         K.colsum(dy, self.g(ln.weight), b=xhat)
@@ -405,6 +422,7 @@ class TrainEngine:
             self._wgrad(S.geo1[l], S.eatt[l], sa.out_proj.weight, sa.out_proj.bias)
             self._wgrad(S.geqkv[l], S.eh[l], sa.in_proj_weight, sa.in_proj_bias)
         self._wgrad(S.geh[0], S.x0, enc.input_fc.weight, enc.input_fc.bias)
+        self._sum_split_parts()
 
     # ------------------------------------------------------------------ convenience
     def predictions(self):

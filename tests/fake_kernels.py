@@ -9,7 +9,11 @@ test tier.  The product never imports this file; on a GPU box the real HIP kerne
 import torch
 
 
-def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None):
+def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1, part_stride=0,
+         asum=None):
+    # (split-K partial buffers: everything lands in slice 0, the other slices keep their zeros)
+    if asum is not None:
+        asum.copy_(A.double().sum(1).to(asum.dtype))
     if ln_bwd is not None:
         xhat, rstd, gamma, dx = ln_bwd
         layernorm_bwd(A, xhat, rstd, gamma, dx)

@@ -77,6 +77,59 @@ def test_gemm_strided_forms_used_by_backward():
     assert float(Cg[:, :N].abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (128, 512, 256), (100, 256, 512), (130, 256, 768), (16, 64, 48)])
+def test_row_block_gemm_and_fused_layernorm_backward(M, N, K):
+    """The per-step sweep's shapes (M <= 256 rows, whole K per workgroup): dX = dY @ W with every epilogue, and the same
+    with the LayerNorm backward applied to the A operand on the fly (dx must also come out)."""
+    from multimodal_transformer_amd import _train_kernels as Kn
+    dev = _dev()
+    dY, W, add, mask = _rand(M, K, seed=1), _rand(K, N, seed=2), _rand(M, N, seed=3), _rand(M, N, seed=4)
+    xhat, rstd, gamma = _rand(M, K, seed=5), _rand(M, seed=6).abs() + 0.5, _rand(K, seed=7)
+    for kw in (dict(), dict(addend=add), dict(mask=mask), dict(addend=add, accumulate=True)):
+        for ln in (False, True):
+            Cc = _rand(M, N, seed=8)
+            Cg = Cc.to(dev)
+            dxc, dxg = torch.zeros(M, K), torch.zeros(M, K, device=dev)
+            kg = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+            F.gemm(dY, W, Cc, ln_bwd=(xhat, rstd, gamma, dxc) if ln else None, **kw)
+            Kn.gemm(dY.to(dev), W.to(dev), Cg, ln_bwd=(xhat.to(dev), rstd.to(dev), gamma.to(dev), dxg) if ln else None, **kg)
+            assert rel_err(Cg.cpu().numpy(), Cc.numpy()) <= 1e-5, (kw.keys(), ln)
+            if ln:
+                assert rel_err(dxg.cpu().numpy(), dxc.numpy()) <= 1e-5
+    # forward form (B operand K-contiguous) on the same kernel
+    Wt = _rand(N, K, seed=9)
+    Cc, Cg = torch.zeros(M, N), torch.zeros(M, N, device=dev)
+    F.gemm(dY, Wt.t(), Cc)
+    Kn.gemm(dY.to(dev), Wt.to(dev).t(), Cg)
+    assert rel_err(Cg.cpu().numpy(), Cc.numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,M,N", [(1536, 256, 256), (1536, 768, 256), (1024, 512, 256), (1000, 36, 100)])
+def test_split_k_weight_gradient_with_bias_sums(R, M, N):
+    """gW = dY^T X with the K range split over 4 workgroup slices (partials at part_stride, summed by the caller) and the
+    bias gradient (column sums of dY) from the same pass; the thin kernel for 2-column outputs."""
+    from multimodal_transformer_amd import _train_kernels as Kn
+    dev = _dev()
+    dY, X = _rand(R, M, seed=1), _rand(R, N, seed=2)
+    stride = M * N + M + 64
+    buf = torch.full((4 * stride,), 7.0, device=dev)
+    gw, gb = buf[:M * N].view(M, N), buf[M * N:M * N + M]
+    Kn.gemm(dY.to(dev).t(), X.to(dev), gw, splitk=4, part_stride=stride, asum=gb)
+    parts = buf.view(4, stride)
+    tot = parts.sum(0).cpu()
+    want_w = (dY.double().t() @ X.double()).float()
+    want_b = dY.double().sum(0).float()
+    assert rel_err(tot[:M * N].view(M, N).numpy(), want_w.numpy()) <= 1e-5
+    assert rel_err(tot[M * N:M * N + M].numpy(), want_b.numpy()) <= 1e-5
+    assert float((parts[:, M * N + M:] - 7.0).abs().max()) == 0.0        # nothing written outside the two regions
+    thin = torch.zeros(M, 2, device=dev)
+    X2 = _rand(R, 2, seed=3)
+    Kn.gemm(dY.to(dev).t(), X2.to(dev), thin)
+    assert rel_err(thin.cpu().numpy(), (dY.double().t() @ X2.double()).float().numpy()) <= 1e-5
+
+
 def test_colsum_and_layernorm():
     from multimodal_transformer_amd import _train_kernels as Kn
     dev = _dev()
