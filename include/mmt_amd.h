@@ -203,6 +203,17 @@ int mmt_pack_lin4_first(const float *w, int ldw, int nparts, int part_rows, int 
                         void *stream);
 size_t mmt_lin4_second_floats(int n, int slice_k, int nslices);
 int mmt_pack_lin4_second(const float *w, int ldw, int n, int slice_k, int nslices, float *dst, void *stream);
+/* All re-layouts of a module in ONE launch (a training step refreshes ~200 packed tensors after every optimizer update):
+ * a device-resident table of jobs, kind 0 = copy `n` floats, 1 = mmt_pack_linear(src, n, k, ldw, col0), 2 =
+ * mmt_pack_lin4_first(src, ldw, nparts, part_rows, slice_rows, k, nslices), 3 = mmt_pack_lin4_second(src, ldw, n,
+ * slice_rows (= slice_k), nslices).  `total` = floats written to dst.  No reference counterpart. */
+typedef struct {
+  const float *src;
+  float *dst;
+  int64_t total;
+  int32_t kind, n, k, ldw, col0, nparts, part_rows, slice_rows, nslices, pad_;
+} mmt_pack_job;
+int mmt_pack_jobs(const mmt_pack_job *table_dev, int njobs, void *stream);
 
 /* ---- Encoder.forward  (Transformer_model.py:45-59; masks of model_utils.py:141-151 built in) --
  * x_st (B,T,n_in) may hold NaN padding; memory (B,T,d) out; pad_mask (B,T) uint8 out (may be NULL). */

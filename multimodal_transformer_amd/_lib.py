@@ -95,6 +95,11 @@ class AttnArgs(C.Structure):
                [(n, C.c_int32) for n in ("B", "H", "Lq", "Lk", "dh", "causal", "causal_offset")] + [("scale", C.c_float)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("src", fptr), ("dst", fptr), ("total", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("kind", "n", "k", "ldw", "col0", "nparts", "part_rows", "slice_rows", "nslices", "pad_")]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [("param", fptr), ("grad", fptr), ("exp_avg", fptr), ("exp_avg_sq", fptr), ("numel", C.c_int64),
                 ("lr_scale", C.c_float), ("pad_", C.c_int32)]
@@ -106,6 +111,7 @@ SIGNATURES = {
     "mmt_version": (C.c_int, []),
     "mmt_packed_linear_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "mmt_pack_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
+    "mmt_pack_jobs": (C.c_int, [fptr, C.c_int, C.c_void_p]),
     "mmt_lin4_first_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mmt_pack_lin4_first": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_lin4_second_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -1044,10 +1044,8 @@ bool mfma4_fits(const mmt_decoder *dec) {
   return true;
 }
 
-__global__ void mmt_pack_lin4_first_kernel(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
-                                           size_t total, float *__restrict__ dst) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+__device__ __forceinline__ float lin4_first_elem(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
+                                                 size_t i) {
   const Lin4 L = lin4(slice_rows / 4, k / 4);
   const int e = i & 3, lane = (i >> 2) & 63, wv = (i >> 8) & 7;
   size_t rest = i >> 11;
@@ -1056,19 +1054,48 @@ __global__ void mmt_pack_lin4_first_kernel(const float *__restrict__ w, int ldw,
   const int p = rest % nparts, g = rest / nparts;
   const int b = lane >> 2, j = lane & 3, cgl = b & (L.cgw - 1), kq = (b >> L.lg_cgw) * L.q + t;
   const int row = p * part_rows + g * slice_rows + (wv * L.cgw + cgl) * 4 + j;
-  dst[i] = kq < k / 4 ? w[(size_t)row * ldw + 4 * kq + e] : 0.f;
+  return kq < k / 4 ? w[(size_t)row * ldw + 4 * kq + e] : 0.f;
 }
-__global__ void mmt_pack_lin4_second_kernel(const float *__restrict__ w, int ldw, int n, int slice_k, size_t total,
-                                            float *__restrict__ dst) {
+__global__ void mmt_pack_lin4_first_kernel(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
+                                           size_t total, float *__restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+  if (i < total) dst[i] = lin4_first_elem(w, ldw, nparts, part_rows, slice_rows, k, i);
+}
+__device__ __forceinline__ float lin4_second_elem(const float *__restrict__ w, int ldw, int n, int slice_k, size_t i) {
   const Lin4 L = lin4(n / 4, slice_k / 4);
   const int e = i & 3, lane = (i >> 2) & 63, wv = (i >> 8) & 7;
   const size_t rest = i >> 11;
   const int t = rest % L.q, g = rest / L.q;
   const int b = lane >> 2, j = lane & 3, cgl = b & (L.cgw - 1), kq = (b >> L.lg_cgw) * L.q + t;
   const int row = (wv * L.cgw + cgl) * 4 + j;
-  dst[i] = kq < slice_k / 4 ? w[(size_t)row * ldw + (size_t)g * slice_k + 4 * kq + e] : 0.f;
+  return kq < slice_k / 4 ? w[(size_t)row * ldw + (size_t)g * slice_k + 4 * kq + e] : 0.f;
+}
+__global__ void mmt_pack_lin4_second_kernel(const float *__restrict__ w, int ldw, int n, int slice_k, size_t total,
+                                            float *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) dst[i] = lin4_second_elem(w, ldw, n, slice_k, i);
+}
+// every re-layout of a module in one launch: blockIdx.y = job
+__global__ __launch_bounds__(256) void mmt_pack_jobs_kernel(const mmt_pack_job *__restrict__ table) {
+  const mmt_pack_job J = table[blockIdx.y];
+  const size_t total = (size_t)J.total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if (J.kind == 0) {
+      v = J.src[i];
+    } else if (J.kind == 1) {        // mmt_pack_linear: [slab][chunk][lane][4] MFMA streaming order, zero padded to 16
+      const int K16 = (J.k + 15) >> 4, e = i & 3, lane = (i >> 2) & 63;
+      const size_t tile = i >> 8;
+      const int chunk = tile % K16, slab = tile / K16;
+      const int row = slab * 16 + (lane & 15), col = chunk * 16 + (lane >> 4) * 4 + e;
+      v = (row < J.n && col < J.k) ? J.src[(size_t)row * J.ldw + J.col0 + col] : 0.f;
+    } else if (J.kind == 2) {
+      v = lin4_first_elem(J.src, J.ldw, J.nparts, J.part_rows, J.slice_rows, J.k, i);
+    } else {
+      v = lin4_second_elem(J.src, J.ldw, J.n, J.slice_rows, i);
+    }
+    J.dst[i] = v;
+  }
 }
 
 }  // namespace
@@ -1099,6 +1126,13 @@ extern "C" int mmt_pack_lin4_second(const float *w, int ldw, int n, int slice_k,
                      total, dst);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : mmt_set_error(MMT_ELAUNCH, "mmt_pack_lin4_second: %s", hipGetErrorString(e));
+}
+
+extern "C" int mmt_pack_jobs(const mmt_pack_job *table_dev, int njobs, void *stream) {
+  if (!table_dev || njobs <= 0 || njobs > 65535) return mmt_set_error(MMT_EINVAL, "mmt_pack_jobs: bad arguments");
+  hipLaunchKernelGGL(mmt_pack_jobs_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)stream, table_dev);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : mmt_set_error(MMT_ELAUNCH, "mmt_pack_jobs: %s", hipGetErrorString(e));
 }
 
 // Geometry the cluster kernels are written for; anything else runs on the persistent kernel.

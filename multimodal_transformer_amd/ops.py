@@ -115,46 +115,67 @@ class _Packer:
         return holder
 
     def finish(self):
-        self.arena.alloc()
+        """Allocate the arena, resolve every job to (source pointer, destination pointer, geometry) in a device-resident
+        table and fill the arena with one kernel launch."""
+        A = self.arena
+        A.alloc()
+        tab, self._keep = [], []
+
+        def flat(t):          # 1-D contiguous view of the source (parameters are; anything else is copied once and kept)
+            v = t.detach().reshape(-1)
+            self._keep.append(v)
+            return v
+
+        def job(kind, src_ptr, dst_off, total, **kw):
+            J = _lib.PackJob()
+            J.src, J.dst, J.total, J.kind = src_ptr, A.addr(dst_off), int(total), kind
+            for k_, v_ in kw.items():
+                setattr(J, k_, int(v_))
+            tab.append(J)
+
+        for jb in self.jobs:
+            if jb[0] == "lin":
+                _, L, w, b, row0, col0, n, k, woff, boff = jb
+                job(1, w.data_ptr() + 4 * row0 * w.stride(0), woff, self.lib.mmt_packed_linear_floats(n, k), n=n, k=k,
+                    ldw=w.stride(0), col0=col0)
+                L.w = A.addr(woff)
+                L.b = None
+                if b is not None:
+                    fb = flat(b)
+                    job(0, fb.data_ptr() + 4 * row0, boff, n, n=n)
+                    L.b = A.addr(boff)
+            elif jb[0] == "lin4a":
+                _, holder, w, nparts, part_rows, slice_rows, nslices, off = jb
+                job(2, w.data_ptr(), off, self.lib.mmt_lin4_first_floats(nparts, slice_rows, w.shape[1], nslices),
+                    ldw=w.stride(0), nparts=nparts, part_rows=part_rows, slice_rows=slice_rows, k=w.shape[1], nslices=nslices)
+                holder[0] = A.addr(off)
+            elif jb[0] == "lin4b":
+                _, holder, w, slice_k, nslices, off = jb
+                job(3, w.data_ptr(), off, self.lib.mmt_lin4_second_floats(w.shape[0], slice_k, nslices), ldw=w.stride(0),
+                    n=w.shape[0], slice_rows=slice_k, nslices=nslices)
+                holder[0] = A.addr(off)
+            elif jb[0] == "norm":
+                _, Nn, g, b, goff, boff = jb
+                fg, fb = flat(g), flat(b)
+                job(0, fg.data_ptr(), goff, fg.numel(), n=fg.numel())
+                job(0, fb.data_ptr(), boff, fb.numel(), n=fb.numel())
+                Nn.g, Nn.b = A.addr(goff), A.addr(boff)
+            else:
+                _, holder, t, off = jb
+                ft = flat(t)
+                job(0, ft.data_ptr(), off, ft.numel(), n=ft.numel())
+                holder[0] = A.addr(off)
+        arr = (_lib.PackJob * len(tab))(*tab)
+        self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(A.device)
+        self._njobs = len(tab)
         return self.run()
 
     def run(self):
-        """(Re)fill the arena from the source tensors: every job reads its source where it lives now, so after an
-        in-place parameter update this refreshes the packed copies without allocating (HIP-graph capturable)."""
-        A = self.arena
-        st = _stream()
-        for job in self.jobs:
-            if job[0] == "lin":
-                _, L, w, b, row0, col0, n, k, woff, boff = job
-                src = w.data_ptr() + 4 * row0 * w.shape[1]
-                _lib.check(self.lib.mmt_pack_linear(C.c_void_p(src), n, k, w.shape[1], col0, C.c_void_p(A.addr(woff)), st),
-                           "mmt_pack_linear")
-                L.w = A.addr(woff)
-                if b is not None:
-                    A.buf[boff:boff + n].copy_(b.detach().reshape(-1)[row0:row0 + n])
-                    L.b = A.addr(boff)
-                else:
-                    L.b = None
-            elif job[0] == "lin4a":
-                _, holder, w, nparts, part_rows, slice_rows, nslices, off = job
-                _lib.check(self.lib.mmt_pack_lin4_first(C.c_void_p(w.data_ptr()), w.stride(0), nparts, part_rows, slice_rows,
-                                                        w.shape[1], nslices, C.c_void_p(A.addr(off)), st), "mmt_pack_lin4_first")
-                holder[0] = A.addr(off)
-            elif job[0] == "lin4b":
-                _, holder, w, slice_k, nslices, off = job
-                _lib.check(self.lib.mmt_pack_lin4_second(C.c_void_p(w.data_ptr()), w.stride(0), w.shape[0], slice_k, nslices,
-                                                         C.c_void_p(A.addr(off)), st), "mmt_pack_lin4_second")
-                holder[0] = A.addr(off)
-            elif job[0] == "norm":
-                _, Nn, g, b, goff, boff = job
-                A.buf[goff:goff + g.numel()].copy_(g.detach().reshape(-1))
-                A.buf[boff:boff + b.numel()].copy_(b.detach().reshape(-1))
-                Nn.g, Nn.b = A.addr(goff), A.addr(boff)
-            else:
-                _, holder, t, off = job
-                A.buf[off:off + t.numel()].copy_(t.detach().reshape(-1))
-                holder[0] = A.addr(off)
-        return A
+        """(Re)fill the arena from the source tensors where they live (same addresses as at finish()): after an in-place
+        parameter update this refreshes every packed copy with one launch and no allocation (HIP-graph capturable)."""
+        if self._njobs:
+            _lib.check(self.lib.mmt_pack_jobs(C.c_void_p(self._table.data_ptr()), self._njobs, _stream()), "mmt_pack_jobs")
+        return self.arena
 
 
 def _copy_struct(dst, src):
