@@ -266,6 +266,10 @@ int mmt_finalize(const float *pred_st, const float *node_pos, const float *gt, i
 /* ---- training ops: all whole-batch, asynchronous on `stream`, graph-capturable ------------------------------------ */
 int mmt_gemm(const mmt_gemm_args *g, void *stream);
 /* out[n] (+)= sum_m a[m*lda+n] * (b ? b[m*ldb+n] : 1), rows with mask[m*ldm+n] <= 0 skipped: bias / LayerNorm grads */
+/* nn.LayerNorm parameter gradients: gw[n] = sum_m dy[m][n]*xhat[m][n], gb[n] = sum_m dy[m][n] (row stride ld for both);
+ * rows dealt over `splitk` slices, slice z writing to gw/gb + z*part_stride (the caller sums the slices) */
+int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld, float *gw, float *gb, int splitk,
+                       long part_stride, void *stream);
 int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,
                float *out, int accumulate, void *stream);
 /* y = [relu](LayerNorm(x + res)) with eps 1e-5; stashes xhat (M,N), rstd (M)   (nn.LayerNorm; MLP.py:13-16) */

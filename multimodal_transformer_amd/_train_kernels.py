@@ -107,6 +107,22 @@ def colsum(a, out, b=None, mask=None, accumulate=False):
                "mmt_colsum")
 
 
+def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
+    """LayerNorm weight / bias gradients in one pass: gw = sum_m dy*xhat, gb = sum_m dy; with ``splitk`` > 1 the rows
+    are dealt over slices and slice z lands at gw/gb + z*``part_stride`` floats (the caller sums the slices)."""
+    ld = _rows(dy, "dy")
+    M, N = dy.shape
+    if tuple(xhat.shape) != (M, N) or _rows(xhat, "xhat") != ld:
+        raise MmtError("ln_param_grads: dy and xhat must have the same shape and row stride")
+    for t, n in ((gw, "gw"), (gb, "gb")):
+        _dev(t, n)
+        if t.numel() != N or not t.is_contiguous():
+            raise MmtError(f"ln_param_grads: {n} must be a contiguous vector of N elements")
+    lib = _lib.load()
+    _lib.check(lib.mmt_ln_param_grads(_p(dy), _p(xhat), M, N, ld, _p(gw), _p(gb), int(splitk), int(part_stride), _stream()),
+               "mmt_ln_param_grads")
+
+
 def _contig2(t, name, shape=None):
     _dev(t, name)
     if not t.is_contiguous() or (shape is not None and tuple(t.shape) != tuple(shape)):

@@ -403,6 +403,43 @@ __global__ __launch_bounds__(256) void mmt_gemm_kernel(mmt_gemm_args g) {
     }
 }
 
+// LayerNorm parameter gradients in one pass: gw[n] = sum_m dy[m][n] * xhat[m][n], gb[n] = sum_m dy[m][n].  The rows are
+// dealt over gridDim.y slices (slice z -> out + z*part_stride, summed by the caller like the split weight gradients).
+__global__ __launch_bounds__(1024) void mmt_ln_param_grads_kernel(const float *__restrict__ dy, const float *__restrict__ xhat, int M,
+                                                                  int N, long ld, float *__restrict__ gw, float *__restrict__ gb,
+                                                                  long part_stride) {
+  __shared__ float pw[64][17], pb[64][17];
+  __shared__ float qw[4][16], qb[4][16];
+  const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, rl = threadIdx.x >> 4;
+  const int per = (M + gridDim.y - 1) / gridDim.y, mb = blockIdx.y * per, me = min(M, mb + per);
+  float sw = 0.f, sb = 0.f;
+  if (c < N) {
+#pragma unroll 4
+    for (int m = mb + rl; m < me; m += 64) {
+      const float d = dy[(size_t)m * ld + c];
+      sw = fmaf(d, xhat[(size_t)m * ld + c], sw);
+      sb += d;
+    }
+  }
+  pw[rl][cl] = sw;
+  pb[rl][cl] = sb;
+  __syncthreads();
+  if (rl < 4) {
+    float tw = 0.f, tb = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      tw += pw[rl * 16 + r][cl];
+      tb += pb[rl * 16 + r][cl];
+    }
+    qw[rl][cl] = tw;
+    qb[rl][cl] = tb;
+  }
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    gw[(size_t)blockIdx.y * part_stride + c] = (qw[0][cl] + qw[1][cl]) + (qw[2][cl] + qw[3][cl]);
+    gb[(size_t)blockIdx.y * part_stride + c] = (qb[0][cl] + qb[1][cl]) + (qb[2][cl] + qb[3][cl]);
+  }
+}
+
 // out[n] (+)= sum_m a[m][n] * (b ? b[m][n] : 1) [only where mask[m][n] > 0]; deterministic order.
 // 16 columns x 64 row-lanes per workgroup: N/16 workgroups, M/64 independent loads per thread.
 __global__ __launch_bounds__(1024) void mmt_colsum_kernel(const float *__restrict__ a, const float *__restrict__ b,
@@ -887,6 +924,15 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM);
   hipLaunchKernelGGL(mmt_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *g);
   return launch_ok("mmt_gemm");
+}
+
+extern "C" int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld, float *gw, float *gb, int splitk,
+                                  long part_stride, void *stream) {
+  if (!dy || !xhat || !gw || !gb || M <= 0 || N <= 0 || splitk < 1 || splitk > 64 || (splitk > 1 && part_stride <= 0))
+    return mmt_set_error(MMT_EINVAL, "mmt_ln_param_grads: bad arguments");
+  hipLaunchKernelGGL(mmt_ln_param_grads_kernel, dim3((N + 15) / 16, splitk), dim3(1024), 0, (hipStream_t)stream, dy, xhat, M, N, ld,
+                     gw, gb, part_stride);
+  return launch_ok("mmt_ln_param_grads");
 }
 
 extern "C" int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,

@@ -148,7 +148,16 @@ class TrainEngine:
         S.geh = [b(Re, d) for _ in range(self.Le + 1)]
         S.gef2, S.gef1 = [b(Re, d) for _ in range(self.Le)], [b(Re, fe) for _ in range(self.Le)]
         S.geh1, S.geo1 = [b(Re, d) for _ in range(self.Le)], [b(Re, d) for _ in range(self.Le)]
-        S.geatt, S.geqkv = [b(Re, d) for _ in range(self.Le)], [b(Re, 3 * d) for _ in range(self.Le)]
+        S.geatt = [b(Re, d) for _ in range(self.Le)]
+        # the buffers that the attention backward kernels accumulate into (dK, dV += ...) share one pool: one fill per step
+        L_ = self.Ld
+        n_geqkv, n_gqkv, n_gmkv = Re * 3 * d, ph * B * 3 * d, Re * 2 * d
+        S.acc_pool = b(self.Le * n_geqkv + L_ * (n_gqkv + n_gmkv))
+        o = 0
+        S.geqkv = []
+        for _ in range(self.Le):
+            S.geqkv.append(S.acc_pool[o:o + n_geqkv].view(Re, 3 * d))
+            o += n_geqkv
         # decoder activations, step-major
         L = self.Ld
         S.pos = b(ph + 1, B, self.n_pos)
@@ -178,8 +187,12 @@ class TrainEngine:
         for n in ("gf2", "gx2", "go2", "ga2", "gcq", "gx1", "go1", "ga1"):
             setattr(S, n, [b(ph, B, d) for _ in range(L)])
         S.gf1 = [b(ph, B, fd) for _ in range(L)]
-        S.gqkv = [b(ph, B, 3 * d) for _ in range(L)]
-        S.gmkv = [b(Re, 2 * d) for _ in range(L)]
+        S.gqkv, S.gmkv = [], []
+        for _ in range(L):
+            S.gqkv.append(S.acc_pool[o:o + n_gqkv].view(ph, B, 3 * d))
+            o += n_gqkv
+            S.gmkv.append(S.acc_pool[o:o + n_gmkv].view(Re, 2 * d))
+            o += n_gmkv
         S.gho = b(ph, B, no)
         S.ghu = [b(ph, B, no) for _ in range(nh)]       # grad wrt relu(LN(.)) output
         S.ghum = [b(ph, B, no) for _ in range(nh)]      # the same, zeroed where relu was inactive
@@ -312,8 +325,11 @@ class TrainEngine:
                 K.add_inplace(self.flat_grad, self.flat_all[z * t:(z + 1) * t])
 
     def _ln_grad(self, dy, xhat, ln):
-        K.colsum(dy, self.g(ln.weight), b=xhat)
-        K.colsum(dy, self.g(ln.bias))
+        if dy.shape[0] >= 512:
+            K.ln_param_grads(dy, xhat, self.g(ln.weight), self.g(ln.bias), splitk=self.SPLITK, part_stride=self.grad_total)
+            self._split_used = True
+        else:
+            K.ln_param_grads(dy, xhat, self.g(ln.weight), self.g(ln.bias))
 
     def _ln_gemm(self, dy, xhat, rstd, gamma, dx, w, out, **kw):
         """dx = LayerNorm backward of dy; out = epi(dx @ w).  One kernel when the row-block GEMM takes the shape (the
@@ -331,9 +347,7 @@ class TrainEngine:
         enc, dec = self.enc, self.dec
         layers = dec.transformer_decoder.layers
         L, nh = self.Ld, len(self.head_hidden)
-        for l in range(L):
-            S.gqkv[l].zero_()
-            S.gmkv[l].zero_()
+        S.acc_pool.zero_()
         for s in range(ph - 1, -1, -1):
             # head: pos[s+1] = pos[s] + out(relu(LN(lin(.)))...)   (MLP.py:12-24, mgcvae.py:445)
             gin = S.G[s + 1]
@@ -410,7 +424,6 @@ class TrainEngine:
             K.gemm(S.gef1[l], lay.linear1.weight, S.geh1[l], addend=S.gef2[l])
             K.layernorm_bwd(S.geh1[l], S.exhat1[l], S.erstd1[l], lay.norm1.weight, S.geo1[l])
             K.gemm(S.geo1[l], sa.out_proj.weight, S.geatt[l])
-            S.geqkv[l].zero_()
             qkv, gq = S.eqkv[l].view(B, T, 3 * d), S.geqkv[l].view(B, T, 3 * d)
             K.attention_bwd(qkv[:, :, 0:d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], S.eprobs[l], S.geatt[l].view(B, T, d),
                             gq[:, :, 0:d], gq[:, :, d:2 * d], gq[:, :, 2 * d:], H, self.scale)

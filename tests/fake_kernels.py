@@ -47,6 +47,11 @@ def colsum(a, out, b=None, mask=None, accumulate=False):
         out.copy_(v)
 
 
+def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
+    gw.copy_((dy.double() * xhat.double()).sum(0).to(gw.dtype))
+    gb.copy_(dy.double().sum(0).to(gb.dtype))
+
+
 def layernorm_fwd(x, res, g, b, y, xhat, rstd, relu=False):
     v = x.double() + (res.double() if res is not None else 0.0)
     mu = v.mean(-1, keepdim=True)
@@ -183,7 +188,7 @@ def ar_decode(eng):
         S.pos[s + 1].copy_(S.pos[s] + S.delta[s])
 
 
-ALL = ("softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
+ALL = ("ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
        "history_prepare", "adamw_table", "adamw_step", "lr_step")
 
 

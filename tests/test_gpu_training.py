@@ -130,6 +130,22 @@ def test_split_k_weight_gradient_with_bias_sums(R, M, N):
     assert rel_err(thin.cpu().numpy(), (dY.double().t() @ X2.double()).float().numpy()) <= 1e-5
 
 
+def test_layernorm_parameter_gradients_one_pass():
+    from multimodal_transformer_amd import _train_kernels as Kn
+    dev = _dev()
+    for M, N in ((1536, 256), (100, 32), (1024, 96)):
+        dy, xh = _rand(M, N, seed=1), _rand(M, N, seed=2)
+        stride = 2 * N + 64
+        buf = torch.full((4 * stride,), 3.0, device=dev)
+        Kn.ln_param_grads(dy.to(dev), xh.to(dev), buf[:N], buf[N:2 * N], splitk=4, part_stride=stride)
+        tot = buf.view(4, stride).sum(0).cpu()
+        assert rel_err(tot[:N].numpy(), (dy.double() * xh.double()).sum(0).float().numpy()) <= 1e-5
+        assert rel_err(tot[N:2 * N].numpy(), dy.double().sum(0).float().numpy()) <= 1e-5
+        one = torch.zeros(2 * N, device=dev)
+        Kn.ln_param_grads(dy.to(dev), xh.to(dev), one[:N], one[N:])
+        assert rel_err(one[:N].cpu().numpy(), (dy.double() * xh.double()).sum(0).float().numpy()) <= 1e-5
+
+
 def test_colsum_and_layernorm():
     from multimodal_transformer_amd import _train_kernels as Kn
     dev = _dev()
