@@ -266,6 +266,11 @@ int mmt_finalize(const float *pred_st, const float *node_pos, const float *gt, i
 /* ---- training ops: all whole-batch, asynchronous on `stream`, graph-capturable ------------------------------------ */
 int mmt_gemm(const mmt_gemm_args *g, void *stream);
 /* out[n] (+)= sum_m a[m*lda+n] * (b ? b[m*ldb+n] : 1), rows with mask[m*ldm+n] <= 0 skipped: bias / LayerNorm grads */
+/* dO = A' @ B as mmt_gemm (optional fused LayerNorm backward, no epilogue, C ignored) handed straight to the backward of an
+ * attention with ONE query per batch element (the decoder's per-step sweep: out_proj's input gradient feeding the attention
+ * backward): dq (=), dk / dv (+=) as mmt_attention_bwd with d_o = dO, which never goes to memory.  M = a->B <= 256, N = H*32. */
+int mmt_gemm_attention_bwd(const mmt_gemm_args *g, const mmt_attn_args *a, float *dq, long dq_bs, float *dk, float *dv,
+                           long dk_bs, long dk_rs, void *stream);
 /* nn.LayerNorm parameter gradients: gw[n] = sum_m dy[m][n]*xhat[m][n], gb[n] = sum_m dy[m][n] (row stride ld for both);
  * rows dealt over `splitk` slices, slice z writing to gw/gb + z*part_stride (the caller sums the slices) */
 int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld, float *gw, float *gb, int splitk,

@@ -128,6 +128,8 @@ SIGNATURES = {
     "mmt_vit_forward": (C.c_int, [C.POINTER(Vit), fptr, C.c_int, fptr, C.c_void_p]),
     "mmt_lane_forward": (C.c_int, [C.POINTER(Lane), fptr, C.c_int, fptr, C.c_void_p]),
     "mmt_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "mmt_gemm_attention_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(AttnArgs), fptr, C.c_long, fptr, fptr, C.c_long, C.c_long,
+                                         C.c_void_p]),
     "mmt_ln_param_grads": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_long, fptr, fptr, C.c_int, C.c_long, C.c_void_p]),
     "mmt_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, fptr, C.c_int, C.c_void_p]),
     "mmt_layernorm_fwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_int, fptr, fptr, fptr, C.c_void_p]),

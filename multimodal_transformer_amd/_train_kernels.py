@@ -39,23 +39,19 @@ def _rows(t, name):
     return t.stride(0)
 
 
-def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1,
-         part_stride=0, asum=None):
-    """Cm (+)= epi(A' @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
-    epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0.
-    ``ln_bwd=(xhat, rstd, g, dx)``: A is the gradient at a LayerNorm output and A' = its LayerNorm backward (the
-    input gradient, also stored to ``dx``), fused into the operand load; without it A' = A.
-    ``splitk`` > 1 (weight gradients): slice z of the K range writes its partial to ``Cm`` + z*``part_stride`` floats
-    (same for ``asum``), the caller sums the slices; ``asum`` (M) receives the row sums of A (the bias gradient)."""
+def _gemm_args(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1,
+               part_stride=0, asum=None):
     _dev(A, "A"), _dev(B, "B")
     M, K = A.shape
     K2, N = B.shape
-    if K2 != K or tuple(Cm.shape) != (M, N):
-        raise MmtError(f"gemm: shapes A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)} do not agree")
+    if K2 != K or (Cm is not None and tuple(Cm.shape) != (M, N)):
+        raise MmtError(f"gemm: shapes A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape) if Cm is not None else None} "
+                       "do not agree")
     g = _lib.GemmArgs()
     g.A, g.sam, g.sak = A.data_ptr(), A.stride(0), A.stride(1)
     g.B, g.sbk, g.sbn = B.data_ptr(), B.stride(0), B.stride(1)
-    g.C, g.ldc = Cm.data_ptr(), _rows(Cm, "C")
+    if Cm is not None:
+        g.C, g.ldc = Cm.data_ptr(), _rows(Cm, "C")
     g.M, g.N, g.K = M, N, K
     if bias is not None:
         _dev(bias, "bias")
@@ -89,8 +85,44 @@ def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=Fal
             if asum.numel() != M or not asum.is_contiguous():
                 raise MmtError("gemm: asum must be a contiguous vector of M elements")
             g.asum = asum.data_ptr()
+    return g
+
+
+def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1,
+         part_stride=0, asum=None):
+    """Cm (+)= epi(A' @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
+    epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0.
+    ``ln_bwd=(xhat, rstd, g, dx)``: A is the gradient at a LayerNorm output and A' = its LayerNorm backward (the
+    input gradient, also stored to ``dx``), fused into the operand load; without it A' = A.
+    ``splitk`` > 1 (weight gradients): slice z of the K range writes its partial to ``Cm`` + z*``part_stride`` floats
+    (same for ``asum``), the caller sums the slices; ``asum`` (M) receives the row sums of A (the bias gradient)."""
+    g = _gemm_args(A, B, Cm, bias, addend, mask, relu, accumulate, ln_bwd, splitk, part_stride, asum)
     lib = _lib.load()
     _lib.check(lib.mmt_gemm(C.byref(g), _stream()), "mmt_gemm")
+
+
+def gemm_attention_bwd_ok(A, nhead, Lk, dh):
+    """Shapes mmt_gemm_attention_bwd takes: the per-step sweep at batch <= 256, head dim 32, <= 16 keys."""
+    M, K = A.shape
+    return M <= 256 and K % 16 == 0 and K <= 256 and dh == 32 and 1 <= Lk <= 16
+
+
+def gemm_attention_bwd(A, B, q, k, v, probs, dq, dk, dv, nhead, scale, ln_bwd=None, probs_strides=None):
+    """d_o = A' @ B (A' as in ``gemm``, no epilogue) is consumed in place by ``attention_bwd`` with one query per batch
+    element: dq (=), dk (+=), dv (+=); d_o itself is not stored."""
+    g = _gemm_args(A, B, None, ln_bwd=ln_bwd)
+    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale, probs_strides=probs_strides)
+    Bn, Lq, d = q.shape
+    Lk = k.shape[1]
+    if Lq != 1 or g.M != Bn or g.N != d:
+        raise MmtError("gemm_attention_bwd: one query per batch element, GEMM output (B, d)")
+    dq_bs, _ = _bld(dq, "dq", Bn, 1, d)
+    dk_bs, dk_rs = _bld(dk, "dk", Bn, Lk, d)
+    if _bld(dv, "dv", Bn, Lk, d) != (dk_bs, dk_rs):
+        raise MmtError("gemm_attention_bwd: dk and dv must share strides")
+    lib = _lib.load()
+    _lib.check(lib.mmt_gemm_attention_bwd(C.byref(g), C.byref(a), _p(dq), dq_bs, _p(dk), _p(dv), dk_bs, dk_rs, _stream()),
+               "mmt_gemm_attention_bwd")
 
 
 def colsum(a, out, b=None, mask=None, accumulate=False):

@@ -198,8 +198,22 @@ void launch_split(const mmt_gemm_args &g, hipStream_t st) {
 // LN = true: the A operand is the gradient at a LayerNorm output; its LayerNorm backward (row statistics over the K
 // columns: the workgroup holds whole rows) is applied in registers before the multiply, and the workgroups of the
 // first column block also store it (ln_dx) for the residual path and the deferred weight-gradient GEMMs.
-template <int NCH, bool BK, bool LN>
-__global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g) {
+template <int DPL>
+__device__ __forceinline__ void ld_dpl(float (&dst)[DPL], rsrc_t r, unsigned off) {
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) dst[e] = bl1(r, off == OOB ? OOB : off + 4u * e);
+}
+// ATT = true (head dim 32, one query per agent: the decoder's per-step sweep): the 16 x 32 tile is the gradient at the output of
+// head blockIdx.x of an attention for 16 agents, and is consumed in place by that attention's backward (dq =, dK / dV +=, as
+// mmt_attention_bwd with Lq = 1) instead of being written out: 16 lanes per agent, the K / dK / dV rows requested together with
+// the GEMM operands.  out_proj's input gradient never goes to memory.
+struct RowsAttn {
+  mmt_attn_args a;
+  float *dq, *dk, *dv;
+  long dq_bs, dk_bs, dk_rs;
+};
+template <int NCH, bool BK, bool LN, bool ATT = false>
+__global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, RowsAttn att) {
   __shared__ float red[4][2][16 * 17];
   __shared__ float stat[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
@@ -229,6 +243,29 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g) {
         for (int e = 0; e < 4; ++e) b[t][i][e] = bl1(rb, ok ? (unsigned)((kk + e) * (int)g.sbk + n) * 4u : OOB);
       }
     }
+  }
+  // attention operands of (agent m0 + tid/16, head blockIdx.x), lane l16 = tid % 16
+  const int ab = m0 + (tid >> 4), l16 = tid & 15;
+  float kr[ATT ? 16 : 1][2], dkr[ATT ? 16 : 1][2], dvr[ATT ? 16 : 1][2], qd[2] = {0.f, 0.f}, pk = 0.f;
+  f32x4 vrow[ATT ? 8 : 1];
+  int Lk = 0;
+  if constexpr (ATT) {
+    const mmt_attn_args &a = att.a;
+    const int h = blockIdx.x;
+    Lk = ab < g.M ? a.Lk : 0;
+    const rsrc_t rk = mk_rsrc(a.k), rv = mk_rsrc(a.v), rdk = mk_rsrc(att.dk), rdv = mk_rsrc(att.dv);
+    const unsigned kb = (unsigned)(ab * (int)a.k_bs + h * 32 + l16 * 2), vb = (unsigned)(ab * (int)a.v_bs + h * 32);
+    const unsigned db = (unsigned)(ab * (int)att.dk_bs + h * 32 + l16 * 2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      ld_dpl<2>(kr[j], rk, j < Lk ? (kb + (unsigned)(j * (int)a.k_rs)) * 4u : OOB);
+      ld_dpl<2>(dkr[j], rdk, j < Lk ? (db + (unsigned)(j * (int)att.dk_rs)) * 4u : OOB);
+      ld_dpl<2>(dvr[j], rdv, j < Lk ? (db + (unsigned)(j * (int)att.dk_rs)) * 4u : OOB);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vrow[c] = bl4(rv, l16 < Lk ? (vb + (unsigned)(l16 * (int)a.v_rs + 4 * c)) * 4u : OOB);
+    ld_dpl<2>(qd, mk_rsrc(a.q), Lk > 0 ? (unsigned)(ab * (int)a.q_bs + h * 32 + l16 * 2) * 4u : OOB);
+    pk = bl1(mk_rsrc(a.probs), l16 < Lk ? (unsigned)((ab * a.H + h) * (int)a.p_hs + l16) * 4u : OOB);
   }
   if constexpr (LN) {
     const float rstd = mok ? g.ln_rstd[m] : 0.f;
@@ -276,6 +313,57 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][t][(4 * kq + r) * 17 + l15] = acc[t][r];
   __syncthreads();
+  if constexpr (ATT) {
+    __shared__ float ct[16][33];                  // dO of head blockIdx.x for the 16 agents
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int o = tid + 256 * it, tt = o >> 8, row = (o & 255) >> 4, col = o & 15, ix = row * 17 + col;
+      ct[row][16 * tt + col] = ((red[0][tt][ix] + red[1][tt][ix]) + red[2][tt][ix]) + red[3][tt][ix];
+    }
+    __syncthreads();
+    const mmt_attn_args &a = att.a;
+    const float *grow = ct[tid >> 4];
+    float dp = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      dp = fmaf(grow[4 * c + 0], vrow[c][0], dp);
+      dp = fmaf(grow[4 * c + 1], vrow[c][1], dp);
+      dp = fmaf(grow[4 * c + 2], vrow[c][2], dp);
+      dp = fmaf(grow[4 * c + 3], vrow[c][3], dp);
+    }
+    const float dP = pk > 0.f ? dp : 0.f;
+    const float dot = row16_sum(pk * dP);
+    const float ds = pk * (dP - dot) * a.scale;
+    const float gd[2] = {grow[l16 * 2], grow[l16 * 2 + 1]};
+    float dqa[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {          // masked / absent keys carry p = ds = 0: exact no-ops
+      const float pj = __shfl(pk, j, 16), dsj = __shfl(ds, j, 16);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        dqa[e] = fmaf(dsj, kr[j][e], dqa[e]);
+        dkr[j][e] = fmaf(dsj, qd[e], dkr[j][e]);
+        dvr[j][e] = fmaf(pj, gd[e], dvr[j][e]);
+      }
+    }
+    if (ab < g.M) {
+      const int h = blockIdx.x;
+      float *dQ = att.dq + (size_t)ab * att.dq_bs + h * 32 + l16 * 2;
+      dQ[0] = dqa[0];
+      dQ[1] = dqa[1];
+      float *dK = att.dk + (size_t)ab * att.dk_bs + h * 32 + l16 * 2, *dV = att.dv + (size_t)ab * att.dk_bs + h * 32 + l16 * 2;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j < Lk) {
+          dK[(size_t)j * att.dk_rs] = dkr[j][0];
+          dK[(size_t)j * att.dk_rs + 1] = dkr[j][1];
+          dV[(size_t)j * att.dk_rs] = dvr[j][0];
+          dV[(size_t)j * att.dk_rs + 1] = dvr[j][1];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int o = tid + 256 * it, t = o >> 8, row = (o & 255) >> 4, col = o & 15;
@@ -295,9 +383,10 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g) {
 template <bool BK, bool LN>
 void launch_rows(const mmt_gemm_args &g, hipStream_t st) {
   const dim3 grid((g.N + 31) / 32, (g.M + 15) / 16), blk(256);
-  if (g.K <= 256) hipLaunchKernelGGL((mmt_gemm_rows_kernel<4, BK, LN>), grid, blk, 0, st, g);
-  else if (g.K <= 512) hipLaunchKernelGGL((mmt_gemm_rows_kernel<8, BK, LN>), grid, blk, 0, st, g);
-  else hipLaunchKernelGGL((mmt_gemm_rows_kernel<12, BK, LN>), grid, blk, 0, st, g);
+  const RowsAttn none = {};
+  if (g.K <= 256) hipLaunchKernelGGL((mmt_gemm_rows_kernel<4, BK, LN>), grid, blk, 0, st, g, none);
+  else if (g.K <= 512) hipLaunchKernelGGL((mmt_gemm_rows_kernel<8, BK, LN>), grid, blk, 0, st, g, none);
+  else hipLaunchKernelGGL((mmt_gemm_rows_kernel<12, BK, LN>), grid, blk, 0, st, g, none);
 }
 
 // ------------------------------------------------------------------------------------------ thin GEMM
@@ -689,11 +778,6 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
 // and lives in registers across the queries; the only memory traffic inside the query loop is q, dO and the
 // probabilities.  (The general kernel above walks the keys with a load -> update -> store chain per key: one memory
 // round trip each, ~10 us for 12 keys.)
-template <int DPL>
-__device__ __forceinline__ void ld_dpl(float (&dst)[DPL], rsrc_t r, unsigned off) {
-#pragma unroll
-  for (int e = 0; e < DPL; ++e) dst[e] = bl1(r, off == OOB ? OOB : off + 4u * e);
-}
 template <int DH>
 __global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, const float *__restrict__ dO, long do_bs, long do_rs,
                                                              float *__restrict__ dq, long dq_bs, long dq_rs,
@@ -924,6 +1008,43 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   dim3 grid((g->N + GBN - 1) / GBN, (g->M + GBM - 1) / GBM);
   hipLaunchKernelGGL(mmt_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *g);
   return launch_ok("mmt_gemm");
+}
+
+// dO = A' @ B (as mmt_gemm with the fused LayerNorm backward when g->ln_xhat is set, no epilogue, C unused), consumed by the
+// backward of an attention with one query per batch element: dq (=), dk/dv (+=) as mmt_attention_bwd with d_o = dO.
+extern "C" int mmt_gemm_attention_bwd(const mmt_gemm_args *g, const mmt_attn_args *a, float *dq, long dq_bs, float *dk, float *dv,
+                                      long dk_bs, long dk_rs, void *stream) {
+  if (!g || !a || !g->A || !g->B || !dq || !dk || !dv) return mmt_set_error(MMT_EINVAL, "mmt_gemm_attention_bwd: null pointer");
+  const bool ak = g->sak == 1 && g->sam % 4 == 0;
+  const bool aligned = (((uintptr_t)g->A | (uintptr_t)g->B) & 15) == 0;
+  const bool shape = ak && g->sbn == 1 && g->K % 16 == 0 && g->K <= 256 && g->M <= 256 && g->M == a->B && a->Lq == 1 && a->dh == 32 &&
+                     g->N == a->H * 32 && a->Lk >= 1 && a->Lk <= 16;
+  const bool plain = !g->bias && !g->addend && !g->mask && !g->relu && !g->accumulate && g->splitk <= 1 && !g->asum;
+  const bool attn_ok = a->q && a->k && a->v && a->probs && (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)dk |
+                                                             (uintptr_t)dv | (uintptr_t)dq) & 15) == 0 &&
+                       ((a->q_bs | a->k_bs | a->k_rs | a->v_bs | a->v_rs | dk_bs | dk_rs | dq_bs) & 3) == 0 && a->p_hs >= a->Lk &&
+                       (double)a->B * (double)std::max(std::max(a->k_bs, a->v_bs), (int64_t)dk_bs) +
+                               (double)a->Lk * (double)std::max(std::max(a->k_rs, a->v_rs), (int64_t)dk_rs) < 5e8 &&
+                       (double)a->B * a->H * (double)a->p_hs < 5e8;
+  const bool ln_ok = !g->ln_xhat || (g->ln_rstd && g->ln_g && g->ld_ln % 4 == 0 && (((uintptr_t)g->ln_xhat | (uintptr_t)g->ln_dx |
+                                                                                    (uintptr_t)g->ln_g) & 15) == 0);
+  if (!aligned || !shape || !plain || !attn_ok || !ln_ok)
+    return mmt_set_error(MMT_EINVAL, "mmt_gemm_attention_bwd: needs the row-block GEMM shape (M = batch <= 256, K <= 256 a multiple "
+                                     "of 16, B operand with unit column stride), head dim 32, one query, <= 16 keys, no epilogue");
+  RowsAttn t;
+  t.a = *a;
+  t.dq = dq, t.dk = dk, t.dv = dv;
+  t.dq_bs = dq_bs, t.dk_bs = dk_bs, t.dk_rs = dk_rs;
+  const dim3 grid(a->H, (g->M + 15) / 16), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define ROWS_ATT(NCHV)                                                                                        \
+  do {                                                                                                        \
+    if (g->ln_xhat) hipLaunchKernelGGL((mmt_gemm_rows_kernel<NCHV, false, true, true>), grid, blk, 0, st, *g, t); \
+    else hipLaunchKernelGGL((mmt_gemm_rows_kernel<NCHV, false, false, true>), grid, blk, 0, st, *g, t);          \
+  } while (0)
+  ROWS_ATT(4);
+#undef ROWS_ATT
+  return launch_ok("mmt_gemm_attention_bwd");
 }
 
 extern "C" int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld, float *gw, float *gb, int splitk,

@@ -341,6 +341,16 @@ class TrainEngine:
             K.layernorm_bwd(dy, xhat, rstd, gamma, dx)
             K.gemm(dx, w, out, **kw)
 
+    def _ln_gemm_attn(self, dy, xhat, rstd, gamma, dx, w, d_o, q, k, v, probs, dq, dk, dv, pstrides):
+        """dx = LayerNorm backward of dy; d_o = dx @ w (out_proj's input gradient); attention backward of one query per
+        agent from d_o.  One kernel when the shapes allow (d_o then never leaves the chip), else the separate ones."""
+        if K.gemm_attention_bwd_ok(dy, self.H, k.shape[1], self.dh):
+            K.gemm_attention_bwd(dy, w, q, k, v, probs, dq, dk, dv, self.H, self.scale, ln_bwd=(xhat, rstd, gamma, dx),
+                                 probs_strides=pstrides)
+            return
+        self._ln_gemm(dy, xhat, rstd, gamma, dx, w, d_o)
+        K.attention_bwd(q, k, v, probs, d_o.view(dy.shape[0], 1, -1), dq, dk, dv, self.H, self.scale, probs_strides=pstrides)
+
     def backward(self):
         """Reverse-time sweep.  ``forward`` must have run; ``S.G[1:]`` holds dL/dpos from the loss kernel."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
@@ -367,21 +377,19 @@ class TrainEngine:
                 self._ln_gemm(S.gx[l + 1][s], S.xhat3[l][s], S.rstd3[l][s], lay.norm3.weight, S.gf2[l][s],
                               lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s])
                 K.gemm(S.gf1[l][s], lay.linear1.weight, S.gx2[l][s], addend=S.gf2[l][s])
-                self._ln_gemm(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s],
-                              ca.out_proj.weight, S.ga2[l][s])
                 mkv, gmkv = S.mkv[l].view(B, T, 2 * d), S.gmkv[l].view(B, T, 2 * d)
-                K.attention_bwd(S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s * T:],
-                                S.ga2[l][s:s + 1].permute(1, 0, 2), S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d],
-                                gmkv[:, :, d:], H, self.scale, probs_strides=(ph * T, T))
+                self._ln_gemm_attn(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s],
+                                   ca.out_proj.weight, S.ga2[l][s],
+                                   S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s * T:],
+                                   S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d], gmkv[:, :, d:], (ph * T, T))
                 K.gemm(S.gcq[l][s], ca.in_proj_weight[:d], S.gx1[l][s], addend=S.go2[l][s])
-                self._ln_gemm(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s],
-                              sa.out_proj.weight, S.ga1[l][s])
                 c, gc = S.qkv[l], S.gqkv[l]
-                K.attention_bwd(c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
-                                c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s * ph:],
-                                S.ga1[l][s:s + 1].permute(1, 0, 2), gc[s:s + 1, :, 0:d].permute(1, 0, 2),
-                                gc[0:s + 1, :, d:2 * d].permute(1, 0, 2), gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), H,
-                                self.scale, probs_strides=(ph * ph, ph))
+                self._ln_gemm_attn(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s],
+                                   sa.out_proj.weight, S.ga1[l][s],
+                                   c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
+                                   c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s * ph:],
+                                   gc[s:s + 1, :, 0:d].permute(1, 0, 2), gc[0:s + 1, :, d:2 * d].permute(1, 0, 2),
+                                   gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), (ph * ph, ph))
                 K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s])
             if s > 0 and self.teacher_forced:      # G[s] = dL/dpos[s] + residual (cumsum) path; tokens are constants
                 K.add_inplace(S.G[s], S.G[s + 1])

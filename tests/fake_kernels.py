@@ -124,6 +124,16 @@ def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale, probs_strides=N
     dv.add_(merge(p.transpose(-1, -2) @ g, Lk).to(dv.dtype))
 
 
+def gemm_attention_bwd_ok(A, nhead, Lk, dh):
+    return True
+
+
+def gemm_attention_bwd(A, B, q, k, v, probs, dq, dk, dv, nhead, scale, ln_bwd=None, probs_strides=None):
+    d_o = torch.zeros(A.shape[0], B.shape[1], dtype=A.dtype)
+    gemm(A, B, d_o, ln_bwd=ln_bwd)
+    attention_bwd(q, k, v, probs, d_o.view(A.shape[0], 1, -1), dq, dk, dv, nhead, scale, probs_strides=probs_strides)
+
+
 def l2_loss_bwd(pos, y, dpos, loss_sum=None):
     ph, B, _ = pos.shape
     diff = pos.double() - y.double().permute(1, 0, 2)
@@ -188,7 +198,7 @@ def ar_decode(eng):
         S.pos[s + 1].copy_(S.pos[s] + S.delta[s])
 
 
-ALL = ("ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
+ALL = ("gemm_attention_bwd_ok", "gemm_attention_bwd", "ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
        "history_prepare", "adamw_table", "adamw_step", "lr_step")
 
 

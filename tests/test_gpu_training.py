@@ -130,6 +130,36 @@ def test_split_k_weight_gradient_with_bias_sums(R, M, N):
     assert rel_err(thin.cpu().numpy(), (dY.double().t() @ X2.double()).float().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,Lk,K,ln", [(128, 8, 12, 256, True), (130, 8, 8, 256, True), (37, 2, 5, 64, False), (128, 8, 1, 256, True)])
+def test_gemm_feeding_attention_backward_in_one_kernel(B, H, Lk, K, ln):
+    """out_proj's input gradient (optionally behind a LayerNorm backward) handed to the attention backward of one query per
+    agent without going to memory == the two kernels run one after the other."""
+    from multimodal_transformer_amd import _train_kernels as Kn
+    dev = _dev()
+    d = H * 32
+    dy, W = _rand(B, K, seed=1), _rand(K, d, seed=2, scale=0.2)
+    xhat, rstd, gamma = _rand(B, K, seed=3), _rand(B, seed=4).abs() + 0.5, _rand(K, seed=5)
+    qkv = _rand(B, Lk, 3 * d, seed=6)
+    q, k, v = qkv[:, :1, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+    o, stash = torch.zeros(B, 1, d), torch.zeros(B * H * 3 * 16)          # probabilities as row 1 of a (B,H,3,16) stash
+    pc = torch.zeros(B * H * Lk)
+    F.attention_fwd(q, k, v, o, pc, H, 32 ** -0.5)
+    stash.view(B, H, 3, 16)[:, :, 1, :Lk] = pc.view(B, H, Lk)
+    acc = _rand(B, Lk, 3 * d, seed=7)
+    want, got = acc.clone(), acc.to(dev)
+    dxc, dxg = torch.zeros(B, K), torch.zeros(B, K, device=dev)
+    F.gemm_attention_bwd(dy, W, q, k, v, stash[16:], want[:, :1, :d], want[:, :, d:2 * d], want[:, :, 2 * d:], H, 32 ** -0.5,
+                         ln_bwd=(xhat, rstd, gamma, dxc) if ln else None, probs_strides=(48, 16))
+    g = qkv.to(dev)
+    assert Kn.gemm_attention_bwd_ok(dy, H, Lk, 32)
+    Kn.gemm_attention_bwd(dy.to(dev), W.to(dev), g[:, :1, :d], g[:, :, d:2 * d], g[:, :, 2 * d:], stash.to(dev)[16:],
+                          got[:, :1, :d], got[:, :, d:2 * d], got[:, :, 2 * d:], H, 32 ** -0.5,
+                          ln_bwd=(xhat.to(dev), rstd.to(dev), gamma.to(dev), dxg) if ln else None, probs_strides=(48, 16))
+    assert rel_err(got.cpu().numpy(), want.numpy()) <= 1e-5
+    if ln:
+        assert rel_err(dxg.cpu().numpy(), dxc.numpy()) <= 1e-5
+
+
 def test_layernorm_parameter_gradients_one_pass():
     from multimodal_transformer_amd import _train_kernels as Kn
     dev = _dev()
