@@ -268,14 +268,14 @@ def main():
                         for p in m.parameters())
         dec_bytes = 4.0 * (n_dec_par + B * (args.history + 1) * hp["transformer"]["in_dim"] + B * ph * 2)
         cluster = args.decoder != "persistent" and B <= 512 and args.history + 1 <= 16 and ph <= 16
-        dec_kernel = ("mmt_dec_phase_kernel x%d + mmt_dec_ckv_kernel (cluster decoder)" % (3 * 6 * ph + 1)) if cluster \
+        dec_kernel = ("mmt_dec_phase4_kernel / mmt_dec_phase_kernel x%d + mmt_dec_ckv_kernel (cluster decoder)" % (3 * 6 * ph + 1)) if cluster \
             else "mmt_decoder_kernel (persistent decoder)"
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01", "traffic_b128_basic_v2.json")
+        tf = os.path.join(ROOT, "profiles", "r01", "traffic_b128_basic_v3.json")
         if cluster and args.mode == "basic" and B == 128 and ph == 12 and args.history == 8 and os.path.exists(tf):
             # HBM-side bytes per decode from separate rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
             traffic = json.load(open(tf))["decoder_bytes_per_predict"]
-            traffic_src = "profiles/r01/traffic_b128_basic_v2.json (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)"
+            traffic_src = "profiles/r01/traffic_b128_basic_v3.json (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)"
         line = {
             "metric": "predicted agents/sec (12-step, batch 128)",
             "value": value, "unit": "agents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
