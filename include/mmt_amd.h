@@ -334,6 +334,17 @@ int mmt_gmm2d_from_cov(const float *cov, long RN, float *log_sigmas, float *corr
 int mmt_map_crop(const uint8_t *const *maps, const int32_t *map_dims, int layers, const int32_t *agent_map,
                  const int32_t *centers, const float *angles_deg, const int32_t *patch_size, int B, float *out, void *stream);
 
+/* ---- batch construction: get_node_timestep_data / get_timesteps_data (model/dataset/preprocessing.py:79-270)
+ * for B (node, timestep) pairs in one launch over a packed fp64 scene table: table rows of node n start at row_off[n] and
+ * cover scene timesteps first[n]..last[n] (environment/node.py:77-139), ncol state columns with the position first.
+ * Outputs as the reference's batch element (preprocessing.py:100-123): first_history_index (B) int64, x (B,max_ht+1,ncol),
+ * y (B,max_ft,npred), x_st / y_st = (. - current position) / scale with NaN padding kept (environment.py:49-61 divides by
+ * 80 regardless of the configured std).  pred_col (npred <= 2 column indices, position prediction) is a HOST array. */
+int mmt_batch_gather(const double *table, const int64_t *row_off, const int32_t *first, const int32_t *last,
+                     const int32_t *node_idx, const int32_t *ts, int B, int max_ht, int max_ft, int ncol,
+                     const int32_t *pred_col, int npred, double scale, int64_t *first_history_index, float *x, float *y,
+                     float *x_st, float *y_st, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+"""ORACLE (test infrastructure, never shipped in the product path).
+
+CPU restatement, in plain numpy loops, of the reference's batch construction:
+  * ``present_nodes``      -- environment/scene.py:103-140 (which nodes are in the scene at which query timestep, and the
+                              order the reference visits them in: dict insertion order of the timesteps, scene order of nodes);
+  * ``node_timestep_data`` -- model/dataset/preprocessing.py:79-123 with environment/node.py:77-117 (``Node.get``: NaN
+                              padding outside the node's lifetime) and environment/environment.py:49-61 (``standardize``
+                              subtracts the mean and divides by 80, whatever std is passed);
+  * ``timesteps_data``     -- preprocessing.py:208-270 (+ ``collate``: stack).
+Pinned against the reference's own outputs in tests/golden/batch.npz (tests/test_oracle_golden.py).
+"""
+import numpy as np
+
+SCALE = 80.0
+
+
+def present_nodes(first, last, timesteps, min_ht, min_ft):
+    """-> list of (timestep, [node indices]) in the reference's visiting order (scene.py:120-140)."""
+    present = {}
+    for n in range(len(first)):                                  # scene.py:122
+        lower, upper = timesteps - min_ht, timesteps + min_ft    # scene.py:126-127
+        mask = (first[n] <= lower) & (upper <= last[n])          # scene.py:128-129
+        for j in np.nonzero(mask)[0]:
+            present.setdefault(int(timesteps[j]), []).append(n)
+    return list(present.items())
+
+
+def node_get(rows, first, last, t0, t1, cols):
+    """Node.get(np.array([t0, t1]), state): inclusive range, NaN outside [first, last] (node.py:101-117)."""
+    length = t1 - t0 + 1
+    out = np.full((length, len(cols)), np.nan)
+    for j in range(length):
+        tt = t0 + j
+        if first <= tt <= last:
+            out[j] = rows[tt - first][cols]
+    return out
+
+
+def node_timestep_data(rows, first, t, max_ht, max_ft, pred_cols):
+    """One batch element (preprocessing.py:100-123); rows = the node's state table (fp64), position in columns 0, 1."""
+    last = first + len(rows) - 1
+    ncol = rows.shape[1]
+    x = node_get(rows, first, last, t - max_ht, t, list(range(ncol)))          # :100,103
+    y = node_get(rows, first, last, t + 1, t + max_ft, list(pred_cols))        # :101,104
+    fhi = max(max_ht - (t - first), 0)                                         # :105
+    rel = np.zeros(ncol)
+    rel[0:2] = x[-1, 0:2]                                                      # :109-110
+    x_st = np.where(np.isnan(x), np.nan, (x - rel) / SCALE)                    # :111-112 -> environment.py:61
+    y_st = np.where(np.isnan(y), np.nan, (y - rel[0:2][:len(pred_cols)]) / SCALE)   # :114-116
+    return fhi, x.astype(np.float32), y.astype(np.float32), x_st.astype(np.float32), y_st.astype(np.float32)
+
+
+def timesteps_data(table, row_off, first, last, timesteps, min_ht, max_ht, max_ft, pred_cols=(0, 1)):
+    """get_timesteps_data (preprocessing.py:236-270): presence needs min_ht history and max_ft future steps (:239-240)."""
+    nodes, out_ts, elems = [], [], []
+    for ts, present in present_nodes(first, last, np.asarray(timesteps), min_ht, max_ft):
+        for n in present:
+            rows = table[row_off[n]:row_off[n] + (last[n] - first[n] + 1)]
+            elems.append(node_timestep_data(rows, int(first[n]), ts, max_ht, max_ft, pred_cols))
+            nodes.append(n)
+            out_ts.append(ts)
+    if not out_ts:
+        return None
+    fhi = np.array([e[0] for e in elems], dtype=np.int64)
+    return (fhi,) + tuple(np.stack([e[k] for e in elems]) for k in range(1, 5)), np.array(nodes), np.array(out_ts)

@@ -1,0 +1,93 @@
+"""Golden vectors for batch construction, produced by the REAL reference:
+``model/dataset/preprocessing.py`` ``get_timesteps_data`` / ``get_node_timestep_data`` on a synthetic scene built from the
+reference's own ``environment`` classes (Environment, Scene, Node, DoubleHeaderNumpyArray).
+
+Run in THIS container only (``/root/reference`` does not travel):  python tests/golden/make_golden_batch.py
+
+Shims, all for things the image lacks or that moved in Python 3.10 (none of them takes part in the arithmetic):
+  * ``collections.Sequence`` alias (environment/data_structures.py:3 imports it from its pre-3.10 place);
+  * ``orjson`` (environment.py:1; only ``dumps`` as a memo key) and ``ncls`` (node.py:5; only MultiNode uses it);
+  * ``vit_pytorch`` as in make_golden.py (model/__init__ imports mgcvae).
+Nothing of the reference is copied: the file holds the synthetic node tables and the tensors the reference returned.
+"""
+import collections
+import collections.abc
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/Transformer"
+
+collections.Sequence = collections.abc.Sequence
+orjson = types.ModuleType("orjson")
+orjson.dumps = lambda o: json.dumps(o, sort_keys=True, default=str).encode()
+sys.modules["orjson"] = orjson
+ncls = types.ModuleType("ncls")
+ncls.NCLS = object
+sys.modules["ncls"] = ncls
+vit = types.ModuleType("vit_pytorch")
+vit.ViT = type("ViT", (torch.nn.Module,), {})
+sys.modules["vit_pytorch"] = vit
+sys.path.insert(0, REF)
+
+from environment import Environment, Scene, Node  # noqa: E402  (reference)
+from model.dataset.preprocessing import get_timesteps_data  # noqa: E402  (reference)
+
+STATE = {"VEHICLE": {"position": ["x", "y"], "velocity": ["x", "y"], "acceleration": ["x", "y"], "heading": ["°", "d°"]}}
+PRED = {"VEHICLE": {"position": ["x", "y"]}}
+COLS = pd.MultiIndex.from_tuples([(e, d) for e, dims in STATE["VEHICLE"].items() for d in dims])
+HP = {"incl_robot_node": False, "map_cnn_encoding": False, "map_vit_encoding": False, "lane_cnn_encoding": False}
+
+
+def main():
+    rng = np.random.default_rng(11)
+    std = {"VEHICLE": {e: {d: {"mean": 0.0, "std": 80.0 if e == "position" else 15.0} for d in dims}
+                       for e, dims in STATE["VEHICLE"].items()}}
+    env = Environment(node_type_list=["VEHICLE"], standardization=std)
+    env.attention_radius = {(env.NodeType.VEHICLE, env.NodeType.VEHICLE): 30.0}
+    T_scene, N = 48, 37
+    scene = Scene(timesteps=T_scene, dt=0.5, name="synthetic")
+    tables, firsts = [], []
+    for n in range(N):
+        first = int(rng.integers(0, 30))
+        length = int(rng.integers(2, T_scene - first + 1))
+        data = rng.normal(size=(length, 8)) * np.array([200., 200., 8., 8., 2., 2., 3., 0.5]) + np.array([500., 900., 0, 0, 0, 0, 0, 0])
+        node = Node(node_type=env.NodeType.VEHICLE, node_id=str(n), data=pd.DataFrame(data, columns=COLS), first_timestep=first)
+        scene.nodes.append(node)
+        tables.append(data)
+        firsts.append(first)
+    out = {"first": np.array(firsts, dtype=np.int32), "lengths": np.array([len(t) for t in tables], dtype=np.int32),
+           "table": np.concatenate(tables, axis=0)}
+    cases = {"one_ts": (np.array([20]), 1, 8, 12, 12), "range": (np.arange(6, 40), 1, 8, 12, 12),
+             "short_hist": (np.arange(0, 47), 0, 4, 3, 3), "eval_like": (np.arange(2, 30), 7, 8, 12, 12)}
+    meta = {}
+    for tag, (ts, min_ht, max_ht, min_ft, max_ft) in cases.items():
+        res = get_timesteps_data(env=env, scene=scene, t=ts, node_type=env.NodeType.VEHICLE, state=STATE, pred_state=PRED,
+                                 edge_types=env.get_edge_types(), min_ht=min_ht, max_ht=max_ht, min_ft=min_ft, max_ft=max_ft,
+                                 hyperparams=HP)
+        batch, nodes, out_ts = res
+        fhi, x, y, x_st, y_st = batch[:5]
+        assert all(b is None for b in batch[5:])
+        out[f"{tag}::t"] = ts
+        out[f"{tag}::first_history_index"] = fhi.numpy()
+        for k, v in (("x", x), ("y", y), ("x_st", x_st), ("y_st", y_st)):
+            out[f"{tag}::{k}"] = v.numpy()
+        out[f"{tag}::nodes"] = np.array([int(nd.id) for nd in nodes], dtype=np.int32)
+        out[f"{tag}::timesteps"] = np.array(out_ts, dtype=np.int32)
+        meta[tag] = dict(min_ht=min_ht, max_ht=max_ht, min_ft=min_ft, max_ft=max_ft, B=len(nodes))
+    assert get_timesteps_data(env=env, scene=scene, t=np.array([47]), node_type=env.NodeType.VEHICLE, state=STATE,
+                              pred_state=PRED, edge_types=env.get_edge_types(), min_ht=1, max_ht=8, min_ft=12, max_ft=12,
+                              hyperparams=HP) is None                        # nothing present -> None (preprocessing.py:268-269)
+    np.savez_compressed(os.path.join(HERE, "batch.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "batch.json"), "w"), indent=1)
+    print(meta)
+
+
+if __name__ == "__main__":
+    main()

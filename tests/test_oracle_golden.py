@@ -92,3 +92,32 @@ def test_kv_cached_restatement_matches_reference(mode, tiny):
         _, h = rs.decoder_ar(w, torch.from_numpy(z["memory"]).double(), pad, None, hp["transformer"]["nhead"], ph,
                              feedback=False, tgt=tgt)
         assert rel_err(h.numpy(), z["decoder_tf"]) <= TOL
+
+
+def test_batch_construction_oracle_matches_reference_outputs():
+    """oracle/batch.py (numpy restatement of get_timesteps_data) == what the reference returned (tests/golden/batch.npz,
+    made by tests/golden/make_golden_batch.py from the real preprocessing.py / environment classes): bit-exact incl. NaNs,
+    same node / timestep order; the vectorised presence logic of the product equals the loop form."""
+    import json
+    import os
+    from oracle import batch as ob
+    GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    from multimodal_transformer_amd.model.dataset.preprocessing import present_nodes
+    z = np.load(os.path.join(GOLD, "batch.npz"))
+    meta = json.load(open(os.path.join(GOLD, "batch.json")))
+    first, lengths, table = z["first"], z["lengths"], z["table"]
+    last = first + lengths - 1
+    row_off = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    for tag, m in meta.items():
+        res = ob.timesteps_data(table, row_off, first, last, z[f"{tag}::t"], m["min_ht"], m["max_ht"], m["max_ft"])
+        (fhi, x, y, x_st, y_st), nodes, ts = res
+        assert np.array_equal(nodes, z[f"{tag}::nodes"]) and np.array_equal(ts, z[f"{tag}::timesteps"])
+        assert np.array_equal(fhi, z[f"{tag}::first_history_index"])
+        for got, key in ((x, "x"), (y, "y"), (x_st, "x_st"), (y_st, "y_st")):
+            want = z[f"{tag}::{key}"]
+            assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (tag, key)
+        ni, tt = present_nodes(first, last, z[f"{tag}::t"], m["min_ht"], m["max_ft"])
+        assert np.array_equal(ni, nodes) and np.array_equal(tt, ts)
+    assert ob.timesteps_data(table, row_off, first, last, np.array([47]), 1, 8, 12) is None
+    ni, _ = present_nodes(first, last, np.array([47]), 1, 12)
+    assert ni.size == 0
