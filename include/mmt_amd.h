@@ -271,6 +271,16 @@ int mmt_gemm(const mmt_gemm_args *g, void *stream);
  * backward): dq (=), dk / dv (+=) as mmt_attention_bwd with d_o = dO, which never goes to memory.  M = a->B <= 256, N = H*32. */
 int mmt_gemm_attention_bwd(const mmt_gemm_args *g, const mmt_attn_args *a, float *dq, long dq_bs, float *dk, float *dv,
                            long dk_bs, long dk_rs, void *stream);
+/* Convolutions of the map CNN as GEMMs for the training path (CNNMapEncoder, nn_component/map_encoder.py:6-36; autograd of
+ * F.leaky_relu(conv(x), 0.2) and of flatten + fc).  Activations are rows (b, y, x) x C columns; patch columns are ordered
+ * (c, ky, kx) like a Conv2d weight.  im2col: cols[(b,oy,ox)][(c,ky,kx)] = leaky(alpha*in + beta, slope), `in` NCHW (nhwc = 0) or
+ * rows-by-channels with row stride ld_in (nhwc = 1).  col2im: the transposed gather, din[(b,y,x)][c] (C columns, contiguous)
+ * = sum of the patch entries that read the pixel, times the activation derivative at z (same layout as din; NULL: none).
+ * ld_cols / ld_dcols / ld_din: row strides (>= the logical widths; the training path pads them to multiples of 4). */
+int mmt_im2col(const float *in, int B, int C, int H, int W, int kh, int kw, int stride, int nhwc, long ld_in, float alpha,
+               float beta, float slope, float *cols, long ld_cols, void *stream);
+int mmt_col2im(const float *dcols, long ld_dcols, int B, int C, int H, int W, int kh, int kw, int stride, const float *z,
+               float slope, float *din, long ld_din, void *stream);
 /* nn.LayerNorm parameter gradients: gw[n] = sum_m dy[m][n]*xhat[m][n], gb[n] = sum_m dy[m][n] (row stride ld for both);
  * rows dealt over `splitk` slices, slice z writing to gw/gb + z*part_stride (the caller sums the slices) */
 int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld, float *gw, float *gb, int splitk,

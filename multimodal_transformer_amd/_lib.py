@@ -132,6 +132,10 @@ SIGNATURES = {
     "mmt_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "mmt_gemm_attention_bwd": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(AttnArgs), fptr, C.c_long, fptr, fptr, C.c_long, C.c_long,
                                          C.c_void_p]),
+    "mmt_im2col": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float,
+                             C.c_float, C.c_float, fptr, C.c_long, C.c_void_p]),
+    "mmt_col2im": (C.c_int, [fptr, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_float, fptr,
+                             C.c_long, C.c_void_p]),
     "mmt_ln_param_grads": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_long, fptr, fptr, C.c_int, C.c_long, C.c_void_p]),
     "mmt_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, fptr, C.c_int, C.c_void_p]),
     "mmt_layernorm_fwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_int, fptr, fptr, fptr, C.c_void_p]),

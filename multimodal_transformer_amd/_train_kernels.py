@@ -139,6 +139,41 @@ def colsum(a, out, b=None, mask=None, accumulate=False):
                "mmt_colsum")
 
 
+def im2col(inp, B, C, H, W, kh, kw, stride, cols, nhwc, alpha=1.0, beta=0.0, slope=1.0):
+    """cols (B*OH*OW, C*kh*kw; row stride >= that) <- patches of ``inp``: NCHW (B,C,H,W) contiguous, or rows (B*H*W, >=C
+    columns) when ``nhwc``; leaky_relu(alpha*v + beta, slope) is applied on load."""
+    _dev(inp, "in"), _dev(cols, "cols")
+    OH, OW = (H - kh) // stride + 1, (W - kw) // stride + 1
+    if tuple(cols.shape) != (B * OH * OW, C * kh * kw) or cols.stride(1) != 1:
+        raise MmtError(f"im2col: cols must be ({B * OH * OW}, {C * kh * kw}) with unit column stride")
+    if nhwc:
+        if inp.dim() != 2 or inp.shape[0] != B * H * W or inp.shape[1] < C or inp.stride(1) != 1:
+            raise MmtError("im2col: nhwc input must be (B*H*W, >=C) rows with unit column stride")
+        ld = inp.stride(0)
+    else:
+        if tuple(inp.shape) != (B, C, H, W) or not inp.is_contiguous():
+            raise MmtError("im2col: nchw input must be a contiguous (B,C,H,W) tensor")
+        ld = 0
+    lib = _lib.load()
+    _lib.check(lib.mmt_im2col(_p(inp), B, C, H, W, kh, kw, stride, int(bool(nhwc)), ld, float(alpha), float(beta), float(slope),
+                              _p(cols), cols.stride(0), _stream()), "mmt_im2col")
+
+
+def col2im(dcols, B, C, H, W, kh, kw, stride, din, z=None, slope=1.0):
+    """din (B*H*W, C) <- transposed im2col of dcols (B*OH*OW, C*kh*kw), times leaky_relu'(z) (z laid out like din) when given.
+    Row strides may exceed the widths."""
+    _dev(dcols, "dcols"), _dev(din, "din")
+    OH, OW = (H - kh) // stride + 1, (W - kw) // stride + 1
+    if tuple(dcols.shape) != (B * OH * OW, C * kh * kw) or dcols.stride(1) != 1:
+        raise MmtError("col2im: dcols shape / column stride")
+    if tuple(din.shape) != (B * H * W, C) or din.stride(1) != 1 or (
+            z is not None and (tuple(z.shape) != tuple(din.shape) or z.stride() != din.stride())):
+        raise MmtError("col2im: din / z must be (B*H*W, C) with unit column stride and equal row strides")
+    lib = _lib.load()
+    _lib.check(lib.mmt_col2im(_p(dcols), dcols.stride(0), B, C, H, W, kh, kw, stride, _p(z), float(slope), _p(din), din.stride(0),
+                              _stream()), "mmt_col2im")
+
+
 def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
     """LayerNorm weight / bias gradients in one pass: gw = sum_m dy*xhat, gb = sum_m dy; with ``splitk`` > 1 the rows
     are dealt over slices and slice z lands at gw/gb + z*``part_stride`` floats (the caller sums the slices)."""

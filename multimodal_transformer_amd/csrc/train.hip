@@ -856,6 +856,58 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, co
   }
 }
 
+// ------------------------------------------------------------------------------------------ convolution as GEMM (training)
+// The map CNN's training path (forward with stash + backward): every conv layer -- and the final flatten + Linear, which is a
+// convolution whose kernel covers the whole feature map -- is im2col + the GEMMs above.  Activations stay as the GEMM leaves
+// them: rows (b, y, x), one column per channel ("NHWC"); the column order of a patch row is (c, ky, kx) = the flattening of a
+// Conv2d weight [Cout][Cin][kh][kw], so weights are used in place.
+//   cols[(b*OH + oy)*OW + ox][(c*kh + ky)*kw + kx] = f(in[b][c][oy*s + ky][ox*s + kx]),  f(v) = alpha*v + beta then leaky_relu(slope)
+// (alpha, beta: the map*2-1 rescale of the first layer; slope: the previous layer's activation applied on load, 1 = none).
+__global__ __launch_bounds__(256) void mmt_im2col_kernel(const float *__restrict__ in, int B, int C, int H, int W, int kh, int kw,
+                                                        int stride, int nhwc, long ld_in, float alpha, float beta, float slope,
+                                                        float *__restrict__ cols, long ld_cols, int OH, int OW) {
+  const int Kc = C * kh * kw;
+  const long total = (long)B * OH * OW * Kc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % Kc);
+    const long row = i / Kc;
+    const int kx = col % kw, ky = (col / kw) % kh, c = col / (kw * kh);
+    const int ox = (int)(row % OW), oy = (int)((row / OW) % OH), b = (int)(row / ((long)OW * OH));
+    const int y = oy * stride + ky, x = ox * stride + kx;
+    float v = nhwc ? in[((long)(b * H + y) * W + x) * ld_in + c] : in[(((long)b * C + c) * H + y) * W + x];
+    v = fmaf(alpha, v, beta);
+    cols[row * ld_cols + col] = v > 0.f ? v : slope * v;
+  }
+}
+// Gather form of the transposed scatter (deterministic): the gradient at input pixel (b, y, x, c) collects every patch entry
+// that read it, and is multiplied by the derivative of the activation that was applied on load (z = the stored pre-activation).
+__global__ __launch_bounds__(256) void mmt_col2im_kernel(const float *__restrict__ dcols, int B, int C, int H, int W, int kh, int kw,
+                                                        int stride, const float *__restrict__ z, float slope,
+                                                        float *__restrict__ din, long ld_dcols, long ld_din, int OH, int OW) {
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float acc = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int ty = y - ky;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= OH) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int tx = x - kx;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= OW) continue;
+        acc += dcols[((long)(b * OH + oy) * OW + ox) * ld_dcols + (c * kh + ky) * kw + kx];
+      }
+    }
+    if (z) acc *= z[pix * ld_din + c] > 0.f ? 1.0f : slope;
+    din[pix * ld_din + c] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ loss / optimizer
 // dpos[t][b][:] = (pos - y) / ||pos - y|| / (B * ph)   with pos laid out [ph][B][2], y laid out [B][ph][2]
 __global__ void mmt_l2_loss_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ y, int B, int ph,
@@ -1045,6 +1097,30 @@ extern "C" int mmt_gemm_attention_bwd(const mmt_gemm_args *g, const mmt_attn_arg
   ROWS_ATT(4);
 #undef ROWS_ATT
   return launch_ok("mmt_gemm_attention_bwd");
+}
+
+extern "C" int mmt_im2col(const float *in, int B, int C, int H, int W, int kh, int kw, int stride, int nhwc, long ld_in, float alpha,
+                          float beta, float slope, float *cols, long ld_cols, void *stream) {
+  if (!in || !cols || B <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || H < kh || W < kw || (nhwc && ld_in < C) ||
+      ld_cols < (long)C * kh * kw)
+    return mmt_set_error(MMT_EINVAL, "mmt_im2col: bad arguments");
+  const int OH = (H - kh) / stride + 1, OW = (W - kw) / stride + 1;
+  const long total = (long)B * OH * OW * C * kh * kw;
+  hipLaunchKernelGGL(mmt_im2col_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)stream, in, B, C,
+                     H, W, kh, kw, stride, nhwc, ld_in, alpha, beta, slope, cols, ld_cols, OH, OW);
+  return launch_ok("mmt_im2col");
+}
+
+extern "C" int mmt_col2im(const float *dcols, long ld_dcols, int B, int C, int H, int W, int kh, int kw, int stride, const float *z,
+                          float slope, float *din, long ld_din, void *stream) {
+  if (!dcols || !din || B <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || H < kh || W < kw || ld_dcols < (long)C * kh * kw ||
+      ld_din < C)
+    return mmt_set_error(MMT_EINVAL, "mmt_col2im: bad arguments");
+  const int OH = (H - kh) / stride + 1, OW = (W - kw) / stride + 1;
+  const long total = (long)B * H * W * C;
+  hipLaunchKernelGGL(mmt_col2im_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 65536)), dim3(256), 0, (hipStream_t)stream, dcols, B,
+                     C, H, W, kh, kw, stride, z, slope, din, ld_dcols, ld_din, OH, OW);
+  return launch_ok("mmt_col2im");
 }
 
 extern "C" int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld, float *gw, float *gb, int splitk,

@@ -37,17 +37,163 @@ class _Stash:
     pass
 
 
+class _MlpTape:
+    """Forward stash and backward of one regression-mode ``Mlp`` (MLP.py:6-30: (Linear, LayerNorm, ReLU) x n + Linear)
+    applied to all ph*B rows (step-major).  ``gin[s]`` receives the gradient at the Mlp's input for step s."""
+
+    def __init__(self, eng, mlp, ph, B):
+        self.hidden = []
+        i = 0
+        while hasattr(mlp.layer_seq, f"lmlp_{i}"):
+            seq = getattr(mlp.layer_seq, f"lmlp_{i}")
+            self.hidden.append((seq[0], seq[1]))
+            i += 1
+        self.out = mlp.layer_seq.out_mlp
+        if not isinstance(self.out, torch.nn.Linear):
+            raise MmtError("only regression-mode Mlps take part in the training step")
+        first = self.hidden[0][0] if self.hidden else self.out
+        self.k_in, self.n_out = first.weight.shape[1], self.out.weight.shape[0]
+        n, b = self.out.weight.shape[1], eng._buf
+        self.ph, self.B, self.R = ph, B, ph * B
+        self.hu = [b(ph, B, n) for _ in self.hidden]
+        self.hxhat = [b(ph, B, n) for _ in self.hidden]
+        self.hrstd = [b(ph, B) for _ in self.hidden]
+        self.tmp = b(ph * B, n) if self.hidden else None
+        self.ghu = [b(ph, B, n) for _ in self.hidden]        # grad wrt relu(LN(.)) output
+        self.ghum = [b(ph, B, n) for _ in self.hidden]       # the same, zeroed where relu was inactive
+        self.ghz = [b(ph, B, n) for _ in self.hidden]        # grad wrt the Linear output feeding the LayerNorm
+        self.gin = b(ph, B, self.k_in)
+
+    def _f2(self, t):
+        return t.view(self.R, t.shape[-1])
+
+    def forward_hidden(self, zin):
+        """zin (R, k_in) -> input of the output Linear (R, n); keeps what the backward reads."""
+        z = zin
+        for i, (lin, ln) in enumerate(self.hidden):
+            K.gemm(z, _t(lin.weight), self.tmp, bias=lin.bias)
+            K.layernorm_fwd(self.tmp, None, ln.weight, ln.bias, self._f2(self.hu[i]), self._f2(self.hxhat[i]),
+                            self.hrstd[i].view(self.R), relu=True)
+            z = self._f2(self.hu[i])
+        return z
+
+    def forward_out(self, z, out, addend=None):
+        K.gemm(z, _t(self.out.weight), out, bias=self.out.bias, addend=addend)
+
+    def backward_step(self, s, gout):
+        gin, w = gout, self.out.weight
+        for i in range(len(self.hidden) - 1, -1, -1):
+            lin, ln = self.hidden[i]
+            K.gemm(gin, w, self.ghu[i][s])
+            K.layernorm_bwd(self.ghu[i][s], self.hxhat[i][s], self.hrstd[i][s], ln.weight, self.ghz[i][s], y_relu=self.hu[i][s],
+                            dy_masked=self.ghum[i][s])
+            gin, w = self.ghz[i][s], lin.weight
+        K.gemm(gin, w, self.gin[s])
+        return self.gin[s]
+
+    def wgrads(self, eng, zin_all, gout_all):
+        z = zin_all
+        for i, (lin, ln) in enumerate(self.hidden):
+            eng._wgrad(self._f2(self.ghz[i]), z, lin.weight, lin.bias)
+            eng._ln_grad(self._f2(self.ghum[i]), self._f2(self.hxhat[i]), ln)
+            z = self._f2(self.hu[i])
+        eng._wgrad(gout_all, z, self.out.weight, self.out.bias)
+
+    def parameters(self):
+        for lin, ln in self.hidden:
+            yield from (lin.weight, lin.bias, ln.weight, ln.bias)
+        yield from (self.out.weight, self.out.bias)
+
+
+class _CnnTape:
+    """CNNMapEncoder (map_encoder.py:6-36) for the training step: every conv -- and flatten + fc, a conv whose kernel covers the
+    whole last feature map -- as im2col + GEMM, pre-activations kept; backward = weight-gradient GEMM, input-gradient GEMM +
+    col2im (with the leaky_relu derivative) per layer.  Activations are rows (b, y, x) x channels."""
+    SLOPE = 0.2                                               # F.leaky_relu(conv(x), 0.2), map_encoder.py:33
+
+    def __init__(self, eng, cnn, B):
+        self.B = B
+        H, W = cnn.in_hw
+        strides = cnn._strides()
+        self.layers = []
+        b = eng._buf
+        for i, conv in enumerate(cnn.convs):
+            Cout, Cin, kh, kw = conv.weight.shape
+            self.layers.append(dict(w=conv.weight, b=conv.bias, Cin=Cin, Cout=Cout, kh=kh, kw=kw, s=int(strides[i]), H=H, W=W))
+            H, W = (H - kh) // strides[i] + 1, (W - kw) // strides[i] + 1
+        Clast = cnn.convs[-1].weight.shape[0]
+        if cnn.fc.weight.shape[1] != Clast * H * W:
+            raise MmtError("CNNMapEncoder: fc width does not match the conv stack")
+        self.layers.append(dict(w=cnn.fc.weight, b=cnn.fc.bias, Cin=Clast, Cout=cnn.fc.weight.shape[0], kh=H, kw=W, s=1, H=H, W=W))
+        r4 = lambda v: (v + 3) & ~3
+        for i, L in enumerate(self.layers):
+            OH, OW = (L["H"] - L["kh"]) // L["s"] + 1, (L["W"] - L["kw"]) // L["s"] + 1
+            rows, kc, co = B * OH * OW, L["Cin"] * L["kh"] * L["kw"], L["Cout"]
+            # row strides padded to multiples of 4 floats (the pad columns stay zero): the weight-gradient GEMM over the
+            # B*OH*OW rows then takes the split-K panel kernel with 16-byte loads instead of the scalar fallback
+            kc4, co4 = r4(kc), r4(co)
+            L.update(rows=rows, kc=kc, kc4=kc4, co4=co4, cols_buf=b(rows, kc4), z_buf=b(rows, co4), dz_buf=b(rows, co4))
+            L["cols"], L["z"], L["dz"] = L["cols_buf"][:, :kc], L["z_buf"][:, :co], L["dz_buf"][:, :co]
+            if i > 0:
+                L["dcols"] = b(rows, kc4)[:, :kc]
+            if rows >= 512:
+                tiles = ((co4 + 31) // 32) * ((kc4 + 31) // 32)
+                L["splitk"] = max(2, min(16, 256 // tiles))
+                L["parts"] = b(L["splitk"], co4 * kc4 + co4)
+                L["tot"] = b(co4 * kc4 + co4)
+        self.n_out = self.layers[-1]["Cout"]
+
+    def parameters(self):
+        for L in self.layers:
+            yield from (L["w"], L["b"])
+
+    def forward(self, maps):
+        """maps (B,C,H,W) in [0,1] -> encoded map (B, n_out); the *2-1 rescale rides in the first im2col (mgcvae.py:289-290)."""
+        inp, nhwc, alpha, beta, slope = maps, False, 2.0, -1.0, 1.0
+        for L in self.layers:
+            K.im2col(inp, self.B, L["Cin"], L["H"], L["W"], L["kh"], L["kw"], L["s"], L["cols"], nhwc, alpha, beta, slope)
+            K.gemm(L["cols"], _t(L["w"].view(L["Cout"], L["kc"])), L["z"], bias=L["b"])
+            inp, nhwc, alpha, beta, slope = L["z"], True, 1.0, 0.0, self.SLOPE
+        return self.layers[-1]["z"]
+
+    def backward(self, eng, g):
+        """g (B, n_out): gradient at the encoded map (any row stride)."""
+        dz = g
+        for i in range(len(self.layers) - 1, -1, -1):
+            L = self.layers[i]
+            gw, gb = eng.g(L["w"]).view(L["Cout"], L["kc"]), eng.g(L["b"])
+            if "parts" in L and dz is L["dz"]:
+                co4, kc4, n = L["co4"], L["kc4"], L["co4"] * L["kc4"]
+                K.gemm(L["dz_buf"].t(), L["cols_buf"], L["parts"][0][:n].view(co4, kc4), splitk=L["splitk"],
+                       part_stride=n + co4, asum=L["parts"][0][n:])
+                K.colsum(L["parts"], L["tot"])
+                gw.copy_(L["tot"][:n].view(co4, kc4)[:L["Cout"], :L["kc"]])
+                gb.copy_(L["tot"][n:n + L["Cout"]])
+            else:
+                eng._wgrad_rows(dz, L["cols"], gw, gb)
+            if i > 0:
+                P = self.layers[i - 1]
+                K.gemm(dz, L["w"].view(L["Cout"], L["kc"]), L["dcols"])
+                K.col2im(L["dcols"], self.B, L["Cin"], L["H"], L["W"], L["kh"], L["kw"], L["s"], P["dz"], z=P["z"], slope=self.SLOPE)
+                dz = P["dz"]
+
+
 class TrainEngine:
-    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic configuration."""
+    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic or Map_encoding_CNN configuration."""
 
     def __init__(self, model, B, T, ph, device=None, teacher_forced=None):
         hp = model.hyperparams
         # non_at_dec (mgcvae.py:310-373): tokens come from the labels, positions are the running sum of the head
         # outputs and are NOT fed back, so no gradient flows through the tokens
         self.teacher_forced = (not hp.get("autoregressive", True)) if teacher_forced is None else bool(teacher_forced)
-        if hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"]:
-            raise MmtError("the HIP training step covers the Basic configuration (BASELINE config 2); "
-                           "map / lane context encoders have no backward kernels yet")
+        if hp["map_vit_encoding"] or hp["lane_cnn_encoding"]:
+            raise MmtError("the HIP training step covers the Basic and Map_encoding_CNN configurations; the ViT / lane context "
+                           "encoders have no backward kernels yet")
+        self.map_mode = bool(hp["map_cnn_encoding"])
+        if self.map_mode and self.teacher_forced:
+            raise MmtError("non_at_dec is only defined for the Basic configuration (mgcvae.py:365-367 does not run)")
+        self.cnn = model._m("map_encoder") if self.map_mode else None
+        self.fuse = model._m("fusion/hist_map") if self.map_mode else None
         self.enc = model._m("node_history_encoder")
         self.dec = model._m("decoder/transformer_decoder")
         self.head = model._m("decoder/MLP")
@@ -68,15 +214,6 @@ class TrainEngine:
         self.f_dec = self.dec.transformer_decoder.layers[0].linear1.weight.shape[0]
         self.n_pos = self.dec.input_fc.weight.shape[1]
         self.n_out = self.dec.output_fc.weight.shape[0]
-        self.head_hidden = []
-        i = 0
-        while hasattr(self.head.layer_seq, f"lmlp_{i}"):
-            seq = getattr(self.head.layer_seq, f"lmlp_{i}")
-            self.head_hidden.append((seq[0], seq[1]))
-            i += 1
-        self.head_out = self.head.layer_seq.out_mlp
-        if not isinstance(self.head_out, torch.nn.Linear):
-            raise MmtError("decoder head must be a regression-mode Mlp")
         self._pdec = None
         self._collect_params(model)
         self._alloc()
@@ -88,8 +225,11 @@ class TrainEngine:
         optimizer exactly like torch skips ``grad is None``."""
         nt = model.node_type
         named = []
-        for key, mod in ((nt + "/node_history_encoder", self.enc), (nt + "/decoder/transformer_decoder", self.dec),
-                         (nt + "/decoder/MLP", self.head)):
+        mods = [(nt + "/node_history_encoder", self.enc), (nt + "/decoder/transformer_decoder", self.dec),
+                (nt + "/decoder/MLP", self.head)]
+        if self.map_mode:
+            mods += [(nt + "/map_encoder", self.cnn), (nt + "/fusion/hist_map", self.fuse)]
+        for key, mod in mods:
             for pn, p in mod.named_parameters():
                 if key.endswith("node_history_encoder") and pn.startswith("output_fc."):
                     continue
@@ -173,12 +313,24 @@ class TrainEngine:
         S.f1 = [b(ph, B, fd) for _ in range(L)]
         S.mkv = [b(Re, 2 * d) for _ in range(L)]
         S.tmp = b(ph * B, d)
-        no, nh = self.n_out, len(self.head_hidden)
-        S.ho = b(ph, B, no)
-        S.hu = [b(ph, B, no) for _ in range(nh)]
-        S.hxhat = [b(ph, B, no) for _ in range(nh)]
-        S.hrstd = [b(ph, B) for _ in range(nh)]
-        S.htmp = b(ph * B, no)
+        no = self.n_out
+        self.head_tape = _MlpTape(self, self.head, ph, B)
+        if self.map_mode:
+            # head input = fusion/hist_map(cat[output_fc(x), encoded_map])   (mgcvae.py:438-443)
+            self.cnn_tape = _CnnTape(self, self.cnn, B)
+            self.fuse_tape = _MlpTape(self, self.fuse, ph, B)
+            md = self.cnn_tape.n_out
+            if self.fuse_tape.k_in != no + md or self.fuse_tape.n_out != self.head_tape.k_in:
+                raise MmtError("fusion/hist_map width does not match output_fc + map encoder")
+            S.hcat = b(ph, B, no + md)
+            S.ho = S.hcat[:, :, :no]                       # output_fc writes straight into its columns of the concatenation
+            S.u = b(ph, B, self.fuse_tape.n_out)
+            S.gmap = b(B * (no + md))
+            self.maps = b(B, *self.cnn.convs[0].weight.shape[1:2], *self.cnn.in_hw)
+        else:
+            if self.head_tape.k_in != no:
+                raise MmtError("decoder/MLP width does not match output_fc")
+            S.ho = b(ph, B, no)
         S.delta = b(ph, B, self.n_pos)
         S.pred = b(B, ph, self.n_pos)                      # autoregressive decode, agent-major (kernel output)
         # decoder gradients, step-major (kept for the deferred weight-gradient GEMMs)
@@ -193,19 +345,21 @@ class TrainEngine:
             o += n_gqkv
             S.gmkv.append(S.acc_pool[o:o + n_gmkv].view(Re, 2 * d))
             o += n_gmkv
-        S.gho = b(ph, B, no)
-        S.ghu = [b(ph, B, no) for _ in range(nh)]       # grad wrt relu(LN(.)) output
-        S.ghum = [b(ph, B, no) for _ in range(nh)]      # the same, zeroed where relu was inactive
-        S.ghz = [b(ph, B, no) for _ in range(nh)]       # grad wrt the Linear output feeding the LayerNorm
+        # gradient at output_fc's output: the head's (or the fusion's) input gradient, first n_out columns
+        S.gho = (self.fuse_tape.gin[:, :, :no] if self.map_mode else self.head_tape.gin)
         self.s = S
 
     # ------------------------------------------------------------------ forward
-    def set_batch(self, x_st, y_st):
+    def set_batch(self, x_st, y_st, maps=None):
         if tuple(x_st.shape) != tuple(self.x_st.shape) or tuple(y_st.shape) != tuple(self.y_st.shape):
             raise MmtError(f"batch shape {tuple(x_st.shape)} / {tuple(y_st.shape)} does not match the engine's "
                            f"{tuple(self.x_st.shape)} / {tuple(self.y_st.shape)}")
         self.x_st.copy_(x_st)
         self.y_st.copy_(y_st)
+        if self.map_mode:
+            if maps is None or tuple(maps.shape) != tuple(self.maps.shape):
+                raise MmtError(f"Map_encoding_CNN training needs maps of shape {tuple(self.maps.shape)}")
+            self.maps.copy_(maps)
 
     def forward(self):
         """Encoder -> memory K/V -> ph decoder steps with position feedback; everything the backward needs is kept."""
@@ -236,6 +390,8 @@ class TrainEngine:
                 S.tok[1:].copy_(self.y_st[:, :ph - 1].permute(1, 0, 2))
         else:
             S.pos[0].copy_(self.x_st[:, -1, 0:self.n_pos])      # start token = standardised current position
+        if self.map_mode:
+            S.enc_map = self.cnn_tape.forward(self.maps)
         if not self.teacher_forced:
             # The autoregressive decode itself runs on the fused decoder kernels (positions only, nothing kept); with the
             # tokens known, every activation the backward needs is recomputed for all ph steps at once: causal
@@ -244,8 +400,7 @@ class TrainEngine:
         self._decoder_all_steps()
         if self.teacher_forced:     # positions = running sum of the head outputs (mgcvae.py:352,370), from pos[0] = 0
             R = ph * B
-            z = (S.hu[-1] if self.head_hidden else S.ho).view(R, self.n_out)
-            K.gemm(z, _t(self.head_out.weight), S.delta.view(R, self.n_pos), bias=self.head_out.bias)
+            self.head_tape.forward_out(self._head_z, S.delta.view(R, self.n_pos))
             K.cumsum_axis(S.delta.view(1, ph, B * self.n_pos), S.pos[1:].view(1, ph, B * self.n_pos), 1)
         # loss value and dL/dpos in one pass (mgcvae.py:614-620)
         self.loss.zero_()
@@ -280,12 +435,16 @@ class TrainEngine:
             K.gemm(f2(S.f1[l]), _t(lay.linear2.weight), S.tmp, bias=lay.linear2.bias, addend=f2(S.x2[l]))
             K.layernorm_fwd(S.tmp, None, lay.norm3.weight, lay.norm3.bias, f2(S.x[l + 1]), f2(S.xhat3[l]),
                             S.rstd3[l].view(R))
-        K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), f2(S.ho), bias=dec.output_fc.bias)
-        z = f2(S.ho)
-        for i, (lin, ln) in enumerate(self.head_hidden):
-            K.gemm(z, _t(lin.weight), S.htmp, bias=lin.bias)
-            K.layernorm_fwd(S.htmp, None, ln.weight, ln.bias, f2(S.hu[i]), f2(S.hxhat[i]), S.hrstd[i].view(R), relu=True)
-            z = f2(S.hu[i])
+        no = self.n_out
+        if self.map_mode:
+            hcat = f2(S.hcat)
+            K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), hcat[:, :no], bias=dec.output_fc.bias)
+            S.hcat[:, :, no:].copy_(S.enc_map.unsqueeze(0).expand(ph, B, -1))
+            self.fuse_tape.forward_out(self.fuse_tape.forward_hidden(hcat), f2(S.u))
+            self._head_z = self.head_tape.forward_hidden(f2(S.u))
+        else:
+            K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), f2(S.ho), bias=dec.output_fc.bias)
+            self._head_z = self.head_tape.forward_hidden(f2(S.ho))
 
     def _ar_decode(self):
         """pos[1:] <- the 12-step autoregressive decode of the current parameters (mgcvae.py:375-449) on the fused
@@ -294,11 +453,12 @@ class TrainEngine:
         if self._pdec is None:      # packed copies alias the parameters: built once, refreshed in place every step
             def dev_sd(m):
                 return {k: v.detach() for k, v in m.state_dict(keep_vars=True).items()}
-            self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head))
+            self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head),
+                                           dev_sd(self.fuse) if self.map_mode else None)
         else:
             self._pdec.repack()
         ops.decoder_forward(self._pdec, S.eh[self.Le].view(self.B, self.T, self.d), S.pad, start_pos=S.pos[0], ph=self.ph,
-                            pred_out=S.pred)
+                            map_feat=S.enc_map if self.map_mode else None, pred_out=S.pred)
         S.pos[1:].copy_(S.pred.permute(1, 0, 2))
 
     # ------------------------------------------------------------------ backward
@@ -356,19 +516,13 @@ class TrainEngine:
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
         enc, dec = self.enc, self.dec
         layers = dec.transformer_decoder.layers
-        L, nh = self.Ld, len(self.head_hidden)
+        L = self.Ld
         S.acc_pool.zero_()
         for s in range(ph - 1, -1, -1):
             # head: pos[s+1] = pos[s] + out(relu(LN(lin(.)))...)   (MLP.py:12-24, mgcvae.py:445)
-            gin = S.G[s + 1]
-            w = self.head_out.weight
-            for i in range(nh - 1, -1, -1):
-                lin, ln = self.head_hidden[i]
-                K.gemm(gin, w, S.ghu[i][s])
-                K.layernorm_bwd(S.ghu[i][s], S.hxhat[i][s], S.hrstd[i][s], ln.weight, S.ghz[i][s], y_relu=S.hu[i][s],
-                                dy_masked=S.ghum[i][s])
-                gin, w = S.ghz[i][s], lin.weight
-            K.gemm(gin, w, S.gho[s])
+            gin = self.head_tape.backward_step(s, S.G[s + 1])
+            if self.map_mode:
+                self.fuse_tape.backward_step(s, gin)          # -> gradient at cat[output_fc(x), encoded_map]
             K.gemm(S.gho[s], dec.output_fc.weight, S.gx[L][s])
             for l in range(L - 1, -1, -1):
                 lay = layers[l]
@@ -414,12 +568,14 @@ class TrainEngine:
             self._wgrad(f2(S.gf2[l]), f2(S.f1[l]), lay.linear2.weight, lay.linear2.bias)
             self._ln_grad(f2(S.gx[l + 1]), f2(S.xhat3[l]), lay.norm3)
         self._wgrad(f2(S.gho), f2(S.x[L]), dec.output_fc.weight, dec.output_fc.bias)
-        z = S.ho
-        for i, (lin, ln) in enumerate(self.head_hidden):
-            self._wgrad(f2(S.ghz[i]), f2(z), lin.weight, lin.bias)
-            self._ln_grad(f2(S.ghum[i]), f2(S.hxhat[i]), ln)
-            z = S.hu[i]
-        self._wgrad(f2(S.G[1:]), f2(z), self.head_out.weight, self.head_out.bias)
+        if self.map_mode:
+            self.head_tape.wgrads(self, f2(S.u), f2(S.G[1:]))
+            self.fuse_tape.wgrads(self, f2(S.hcat), f2(self.head_tape.gin))
+            # d encoded_map = sum over the steps of the concatenation's last columns, then back through the CNN
+            K.colsum(self.fuse_tape.gin.view(ph, B * self.fuse_tape.k_in), S.gmap)
+            self.cnn_tape.backward(self, S.gmap.view(B, self.fuse_tape.k_in)[:, self.n_out:])
+        else:
+            self.head_tape.wgrads(self, f2(S.ho), f2(S.G[1:]))
         # ---- encoder: d memory = sum over decoder layers of d(memory K/V) W_kv
         gmem = S.geh[self.Le]
         for l, lay in enumerate(layers):
@@ -469,15 +625,15 @@ class _TrainLossFn(torch.autograd.Function):
         return (None,) + tuple(eng.g(p) for _, p in eng.named_params)
 
 
-def train_loss_with_graph(model, x_st, y_st, ph, teacher_forced=False):
-    """``MultimodalGenerativeCVAE.train_loss`` body for the Basic configuration: a scalar that carries autograd."""
+def train_loss_with_graph(model, x_st, y_st, ph, teacher_forced=False, maps=None):
+    """``MultimodalGenerativeCVAE.train_loss`` body (Basic / Map_encoding_CNN): a scalar that carries autograd."""
     B, T, _ = x_st.shape
     key = (B, T, ph, bool(teacher_forced))
     cache = model.__dict__.setdefault("_train_engines", {})
     eng = cache.get(key)
     if eng is None:
         eng = cache[key] = TrainEngine(model, B, T, ph, teacher_forced=teacher_forced)
-    eng.set_batch(x_st, y_st)
+    eng.set_batch(x_st, y_st, maps)
     return _TrainLossFn.apply(eng, *[p for _, p in eng.named_params])
 
 
@@ -539,9 +695,9 @@ class Trainer:
         with torch.cuda.graph(self._g_opt):
             self._opt()
 
-    def step(self, x_st, y_st):
+    def step(self, x_st, y_st, maps=None):
         """One optimisation step on this rank's shard; returns the local loss as a 1-element device tensor."""
-        self.engine.set_batch(x_st, y_st)
+        self.engine.set_batch(x_st, y_st, maps)
         if self.use_graph:
             if self._g_fb is None:
                 self._capture()
@@ -558,7 +714,9 @@ class Trainer:
         self.steps_done += 1
         # the kernels wrote the parameters through raw pointers (no torch version bump): drop the packed
         # inference copies so that the next predict() re-packs the updated weights
-        for mod in (self.engine.enc, self.engine.dec, self.engine.head):
+        for mod in (self.engine.enc, self.engine.dec, self.engine.head, self.engine.cnn, self.engine.fuse):
+            if mod is None:
+                continue
             mod.__dict__.pop("_pack_cache", None)
             mod.__dict__.pop("_pack_cache_dec", None)
         return self.engine.loss

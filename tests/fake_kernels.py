@@ -47,6 +47,27 @@ def colsum(a, out, b=None, mask=None, accumulate=False):
         out.copy_(v)
 
 
+def _as_nchw(inp, B, C, H, W, nhwc):
+    return inp[:, :C].reshape(B, H, W, C).permute(0, 3, 1, 2) if nhwc else inp
+
+
+def im2col(inp, B, C, H, W, kh, kw, stride, cols, nhwc, alpha=1.0, beta=0.0, slope=1.0):
+    v = _as_nchw(inp, B, C, H, W, nhwc).double() * alpha + beta
+    v = torch.where(v > 0, v, slope * v)
+    u = torch.nn.functional.unfold(v, (kh, kw), stride=stride)            # (B, C*kh*kw, OH*OW), column order (c, ky, kx)
+    cols.copy_(u.permute(0, 2, 1).reshape(cols.shape).to(cols.dtype))
+
+
+def col2im(dcols, B, C, H, W, kh, kw, stride, din, z=None, slope=1.0):
+    OH, OW = (H - kh) // stride + 1, (W - kw) // stride + 1
+    u = dcols.double().reshape(B, OH * OW, C * kh * kw).permute(0, 2, 1)
+    g = torch.nn.functional.fold(u, (H, W), (kh, kw), stride=stride)      # (B, C, H, W)
+    g = g.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    if z is not None:
+        g = g * torch.where(z > 0, torch.ones_like(g), torch.full_like(g, slope))
+    din.copy_(g.to(din.dtype))
+
+
 def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
     gw.copy_((dy.double() * xhat.double()).sum(0).to(gw.dtype))
     gb.copy_(dy.double().sum(0).to(gb.dtype))
@@ -190,15 +211,13 @@ def ar_decode(eng):
     running the engine's own all-steps pass once per step with the teacher-forced wiring (causal attention makes step s
     independent of the tokens after it) and feeding position s+1 = position s + head output back as the next token."""
     S, ph = eng.s, eng.ph
-    dec, f2 = eng.dec, (lambda t: t.view(ph * eng.B, t.shape[-1]))
     for s in range(ph):
         eng._decoder_all_steps()
-        z = f2(S.hu[-1]) if eng.head_hidden else f2(S.ho)
-        gemm(z, eng.head_out.weight.t(), f2(S.delta), bias=eng.head_out.bias)
+        eng.head_tape.forward_out(eng._head_z, S.delta.view(ph * eng.B, -1))
         S.pos[s + 1].copy_(S.pos[s] + S.delta[s])
 
 
-ALL = ("gemm_attention_bwd_ok", "gemm_attention_bwd", "ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
+ALL = ("im2col", "col2im", "gemm_attention_bwd_ok", "gemm_attention_bwd", "ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
        "history_prepare", "adamw_table", "adamw_step", "lr_step")
 
 

@@ -306,6 +306,67 @@ def test_tiny_step_matches_reference_autograd_and_adamw():
             assert ok, (key, e)
 
 
+@pytest.mark.parametrize("B,C,H,W,kh,kw,stride,nhwc", [(3, 3, 20, 20, 5, 5, 2, False), (2, 10, 12, 12, 5, 5, 1, True),
+                                                       (4, 1, 6, 6, 6, 6, 1, True), (2, 4, 9, 7, 3, 2, 2, True)])
+def test_im2col_col2im_match_unfold_fold(B, C, H, W, kh, kw, stride, nhwc):
+    from multimodal_transformer_amd import _train_kernels as Kn
+    dev = _dev()
+    OH, OW = (H - kh) // stride + 1, (W - kw) // stride + 1
+    inp = _rand(B * H * W, C + 3, seed=1)[:, :C] if nhwc else _rand(B, C, H, W, seed=1)       # nhwc: rows wider than C
+    cols_c, cols_g = torch.zeros(B * OH * OW, C * kh * kw), torch.zeros(B * OH * OW, C * kh * kw, device=dev)
+    ig = (_rand(B * H * W, C + 3, seed=1).to(dev)[:, :C] if nhwc else inp.to(dev))
+    for alpha, beta, slope in ((1.0, 0.0, 1.0), (2.0, -1.0, 1.0), (1.0, 0.0, 0.2)):
+        F.im2col(inp, B, C, H, W, kh, kw, stride, cols_c, nhwc, alpha, beta, slope)
+        Kn.im2col(ig, B, C, H, W, kh, kw, stride, cols_g, nhwc, alpha, beta, slope)
+        assert rel_err(cols_g.cpu().numpy(), cols_c.numpy()) <= 1e-6
+    dcols = _rand(B * OH * OW, C * kh * kw, seed=2)
+    zc = _rand(B * H * W, C, seed=3)
+    for z, slope in ((None, 1.0), (zc, 0.2)):
+        dc, dg = torch.zeros(B * H * W, C), torch.zeros(B * H * W, C, device=dev)
+        F.col2im(dcols, B, C, H, W, kh, kw, stride, dc, z=z, slope=slope)
+        Kn.col2im(dcols.to(dev), B, C, H, W, kh, kw, stride, dg, z=z.to(dev) if z is not None else None, slope=slope)
+        assert rel_err(dg.cpu().numpy(), dc.numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("tiny", [True, False])
+def test_map_cnn_step_matches_reference(tiny):
+    """Map_encoding_CNN training step (CNN map encoder + fusion/hist_map train, own learning rate for the map encoder):
+    tiny config element-wise against the reference's autograd, full config (B=128, 100x100 rasters) by gradient norms, the
+    first 256 elements of every gradient and the post-AdamW parameters."""
+    from multimodal_transformer_amd import training
+    dev = _dev()
+    z, meta = load_golden("tiny_map_cnn" if tiny else "full_map_cnn")
+    hp, B, ph = hp_for("map_cnn", tiny)
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, tiny, z)
+    batch = batch_for("map_cnn", tiny)
+    x_st, y_st, maps = (torch.from_numpy(batch[k]).to(dev) for k in ("x_st", "y_st", "map"))
+    tr = training.Trainer(model, B, x_st.shape[1], ph, use_graph=not tiny)
+    loss = tr.step(x_st, y_st, maps)
+    assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
+    want = {k for k, v in meta["grad_norms"].items() if v is not None}
+    assert set(tr.engine.grad_by_name) == want
+    for name, g in tr.engine.grad_by_name.items():
+        if tiny:
+            assert rel_err(g.cpu().numpy(), z["grad::" + name]) <= TOL, name
+        else:
+            wn = meta["grad_norms"][name]
+            assert abs(float(g.double().norm()) - wn) <= 1e-3 * wn + 1e-9, name
+            rms = wn / np.sqrt(g.numel())
+            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= 5e-4, name
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            lr = 0.0008 if "map_encoder" in key else hp["learning_rate"]
+            if tiny:
+                ok, e = check_post_step(p.detach().cpu().numpy(), z["post::" + key],
+                                        z["grad::" + key] if "grad::" + key in z.files else None, lr)
+            else:
+                ok, e = check_post_step(p.detach().reshape(-1)[:256].cpu().numpy(), z["posthead::" + key],
+                                        z["gradhead::" + key] if "gradhead::" + key in z.files else None, lr)
+            assert ok, (key, e)
+
+
 def test_full_config_step_matches_reference_gradient_norms():
     """BASELINE config 2 per-GPU shard (B=128, T=9, ph=12, 8.0 M parameters): loss, per-parameter gradient norms
     and the post-AdamW weight checksums of the reference."""
