@@ -149,14 +149,15 @@ def cpu_train_baseline(hp, batch, ph, max_seconds=25.0):
                       "oracle/reference_form.py, dropout 0, anomaly detection off"}
 
 
-def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, dist, with_map=False):
+def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, dist, with_map=False, with_lanes=False):
     """BASELINE config 2: Basic transformer training step (fwd + bwd + clip + AdamW), data-parallel with one flat
     RCCL gradient all-reduce per step, 128 agents per GPU (global batch 128 * world)."""
     from multimodal_transformer_amd.training import Trainer
     hp["autoregressive"] = True
-    batches = [make_batch(B, history, ph, seed=100 + 10 * rank + i, with_map=with_map) for i in range(4)]
-    dev_batches = [(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev)) +
-                   ((torch.from_numpy(b["map"]).to(dev),) if with_map else ()) for b in batches]
+    batches = [make_batch(B, history, ph, seed=100 + 10 * rank + i, with_map=with_map, with_lanes=with_lanes) for i in range(4)]
+    dev_batches = [(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev),
+                    torch.from_numpy(b["map"]).to(dev) if with_map else None,
+                    torch.from_numpy(b["lanes"]).to(dev) if with_lanes else None) for b in batches]
     tr = Trainer(model, B, history + 1, ph, use_graph=True)
     for i in range(warmup):
         tr.step(*dev_batches[i % 4])
@@ -252,10 +253,11 @@ def main():
     assert torch.isfinite(res).all()
 
     train = None
-    if args.mode in ("basic", "map_cnn") and not args.no_train:       # every rank takes part (all-reduce inside)
+    if args.mode in ("basic", "map_cnn", "lane_cnn") and not args.no_train:       # every rank takes part (all-reduce inside)
         try:
             train = bench_train(model, hp, dev, B, args.history, ph, rank, world, args.train_steps,
-                                max(3, min(args.warmup, 5)), dist if distributed else None, with_map=(args.mode == "map_cnn"))
+                                max(3, min(args.warmup, 5)), dist if distributed else None, with_map=(args.mode == "map_cnn"),
+                                with_lanes=(args.mode == "lane_cnn"))
         except Exception as e:       # the headline metric must survive a failure of the extra leg
             train = {"error": f"{type(e).__name__}: {e}"}
 

@@ -226,10 +226,10 @@ class MultimodalGenerativeCVAE(object):
                    prediction_horizon):
         """mgcvae.py:559-627 -> (loss, reg_loss), standardised units, dropout-free graph.
 
-        Basic and Map_encoding_CNN configurations: the returned scalar carries autograd -- ``loss.backward()`` runs the HIP
+        Basic, Map_encoding_CNN and Lane_encoding_CNN configurations: the returned scalar carries autograd -- ``loss.backward()`` runs the HIP
         backward (training.py) and fills ``.grad`` of every parameter, so the reference's loop (train.py:244-253) works
         unchanged; ``training.Trainer`` is the fused, graph-replayed equivalent of that whole loop body.
-        ViT / lane configurations: forward value only (their context encoders have no backward kernels yet)."""
+        ViT configuration: forward value only (no backward kernels, parity unpinned)."""
         hp = self.hyperparams
         basic = not (hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"])
         map_cnn = bool(hp["map_cnn_encoding"]) and hp["autoregressive"]
@@ -244,6 +244,10 @@ class MultimodalGenerativeCVAE(object):
             from ..training import train_loss_with_graph
             loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon,
                                          maps=map.contiguous())
+        elif hp["lane_cnn_encoding"] and hp["autoregressive"]:      # lane encoder and fusion/lane_hist train too
+            from ..training import train_loss_with_graph
+            loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon,
+                                         lanes=inputs_lane.contiguous())
         else:
             loss = self._loss(inputs, inputs_st, inputs_lane, labels, labels_st, map, prediction_horizon, False,
                               ModeKeys.EVAL)

@@ -111,20 +111,22 @@ class _CnnTape:
     col2im (with the leaky_relu derivative) per layer.  Activations are rows (b, y, x) x channels."""
     SLOPE = 0.2                                               # F.leaky_relu(conv(x), 0.2), map_encoder.py:33
 
-    def __init__(self, eng, cnn, B):
-        self.B = B
-        H, W = cnn.in_hw
-        strides = cnn._strides()
+    def __init__(self, eng, convs, strides, fc, in_hw, B, alpha=1.0, beta=0.0):
+        """convs: Conv2d or Conv1d modules (a Conv1d is a conv over a 1 x W map); alpha, beta: rescale of the raw input."""
+        self.B, self.alpha, self.beta = B, float(alpha), float(beta)
+        H, W = in_hw
         self.layers = []
         b = eng._buf
-        for i, conv in enumerate(cnn.convs):
-            Cout, Cin, kh, kw = conv.weight.shape
+        for i, conv in enumerate(convs):
+            shp = tuple(conv.weight.shape)
+            Cout, Cin, kh, kw = shp if len(shp) == 4 else (shp[0], shp[1], 1, shp[2])
             self.layers.append(dict(w=conv.weight, b=conv.bias, Cin=Cin, Cout=Cout, kh=kh, kw=kw, s=int(strides[i]), H=H, W=W))
-            H, W = (H - kh) // strides[i] + 1, (W - kw) // strides[i] + 1
-        Clast = cnn.convs[-1].weight.shape[0]
-        if cnn.fc.weight.shape[1] != Clast * H * W:
-            raise MmtError("CNNMapEncoder: fc width does not match the conv stack")
-        self.layers.append(dict(w=cnn.fc.weight, b=cnn.fc.bias, Cin=Clast, Cout=cnn.fc.weight.shape[0], kh=H, kw=W, s=1, H=H, W=W))
+            H, W = (H - kh) // int(strides[i]) + 1, (W - kw) // int(strides[i]) + 1
+        Clast = self.layers[-1]["Cout"]
+        if fc.weight.shape[1] != Clast * H * W:
+            raise MmtError("conv encoder: fc width does not match the conv stack")
+        self.layers.append(dict(w=fc.weight, b=fc.bias, Cin=Clast, Cout=fc.weight.shape[0], kh=H, kw=W, s=1, H=H, W=W))
+        self.in_shape = (B, self.layers[0]["Cin"], in_hw[0], in_hw[1])
         r4 = lambda v: (v + 3) & ~3
         for i, L in enumerate(self.layers):
             OH, OW = (L["H"] - L["kh"]) // L["s"] + 1, (L["W"] - L["kw"]) // L["s"] + 1
@@ -147,9 +149,9 @@ class _CnnTape:
         for L in self.layers:
             yield from (L["w"], L["b"])
 
-    def forward(self, maps):
-        """maps (B,C,H,W) in [0,1] -> encoded map (B, n_out); the *2-1 rescale rides in the first im2col (mgcvae.py:289-290)."""
-        inp, nhwc, alpha, beta, slope = maps, False, 2.0, -1.0, 1.0
+    def forward(self, raw):
+        """raw (B,C,H,W) -> features (B, n_out); the input rescale (map*2-1, mgcvae.py:289-290) rides in the first im2col."""
+        inp, nhwc, alpha, beta, slope = raw, False, self.alpha, self.beta, 1.0
         for L in self.layers:
             K.im2col(inp, self.B, L["Cin"], L["H"], L["W"], L["kh"], L["kw"], L["s"], L["cols"], nhwc, alpha, beta, slope)
             K.gemm(L["cols"], _t(L["w"].view(L["Cout"], L["kc"])), L["z"], bias=L["b"])
@@ -179,21 +181,29 @@ class _CnnTape:
 
 
 class TrainEngine:
-    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic or Map_encoding_CNN configuration."""
+    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic, Map_encoding_CNN or Lane_encoding_CNN configuration."""
 
     def __init__(self, model, B, T, ph, device=None, teacher_forced=None):
         hp = model.hyperparams
         # non_at_dec (mgcvae.py:310-373): tokens come from the labels, positions are the running sum of the head
         # outputs and are NOT fed back, so no gradient flows through the tokens
         self.teacher_forced = (not hp.get("autoregressive", True)) if teacher_forced is None else bool(teacher_forced)
-        if hp["map_vit_encoding"] or hp["lane_cnn_encoding"]:
-            raise MmtError("the HIP training step covers the Basic and Map_encoding_CNN configurations; the ViT / lane context "
-                           "encoders have no backward kernels yet")
+        if hp["map_vit_encoding"]:
+            raise MmtError("the HIP training step covers the Basic, Map_encoding_CNN and Lane_encoding_CNN configurations; the "
+                           "ViT map encoder has no backward kernels (and no pinned parity)")
         self.map_mode = bool(hp["map_cnn_encoding"])
-        if self.map_mode and self.teacher_forced:
+        self.lane_mode = bool(hp["lane_cnn_encoding"])
+        if (self.map_mode or self.lane_mode) and self.teacher_forced:
             raise MmtError("non_at_dec is only defined for the Basic configuration (mgcvae.py:365-367 does not run)")
         self.cnn = model._m("map_encoder") if self.map_mode else None
         self.fuse = model._m("fusion/hist_map") if self.map_mode else None
+        # lane configuration (mgcvae.py:395-424): memory <- fusion/lane_hist(cat[memory, lane feature]); the reference feeds
+        # lane 0's feature to all three decodes (:404), which are therefore identical: one decode, loss = its loss (:603-612)
+        self.lane_enc = model._m("lane_encoder") if self.lane_mode else None
+        self.memfuse = model._m("fusion/lane_hist") if self.lane_mode else None
+        if self.lane_mode:
+            self.n_lane, self.n_samp = int(hp["max_lane_num"]), int(hp["sample_num"])
+            self.lane_emb = int(hp["lane_encoder"][model.node_type]["embedding_size"])
         self.enc = model._m("node_history_encoder")
         self.dec = model._m("decoder/transformer_decoder")
         self.head = model._m("decoder/MLP")
@@ -229,6 +239,8 @@ class TrainEngine:
                 (nt + "/decoder/MLP", self.head)]
         if self.map_mode:
             mods += [(nt + "/map_encoder", self.cnn), (nt + "/fusion/hist_map", self.fuse)]
+        if self.lane_mode:
+            mods += [(nt + "/lane_encoder", self.lane_enc), (nt + "/fusion/lane_hist", self.memfuse)]
         for key, mod in mods:
             for pn, p in mod.named_parameters():
                 if key.endswith("node_history_encoder") and pn.startswith("output_fc."):
@@ -317,7 +329,7 @@ class TrainEngine:
         self.head_tape = _MlpTape(self, self.head, ph, B)
         if self.map_mode:
             # head input = fusion/hist_map(cat[output_fc(x), encoded_map])   (mgcvae.py:438-443)
-            self.cnn_tape = _CnnTape(self, self.cnn, B)
+            self.cnn_tape = _CnnTape(self, self.cnn.convs, self.cnn._strides(), self.cnn.fc, self.cnn.in_hw, B, 2.0, -1.0)
             self.fuse_tape = _MlpTape(self, self.fuse, ph, B)
             md = self.cnn_tape.n_out
             if self.fuse_tape.k_in != no + md or self.fuse_tape.n_out != self.head_tape.k_in:
@@ -345,12 +357,25 @@ class TrainEngine:
             o += n_gqkv
             S.gmkv.append(S.acc_pool[o:o + n_gmkv].view(Re, 2 * d))
             o += n_gmkv
+        if self.lane_mode:
+            if T < self.n_lane:
+                raise MmtError("lane decoding needs history length >= max_lane_num (mgcvae.py:404)")
+            nl = self.n_lane
+            stride = getattr(self.lane_enc, "stride", None) or self.lane_enc.convs[0].stride[0]
+            self.lane_tape = _CnnTape(self, self.lane_enc.convs, [stride], self.lane_enc.fc, (1, self.n_samp), B * nl)
+            self.memfuse_tape = _MlpTape(self, self.memfuse, 1, Re)
+            lf = self.lane_tape.n_out
+            if self.memfuse_tape.k_in != d + lf or self.memfuse_tape.n_out != d:
+                raise MmtError("fusion/lane_hist width does not match memory + lane feature")
+            self.lanes = b(B, nl, self.n_samp, self.lane_emb)
+            S.memcat, S.memf, S.gmemf = b(Re, d + lf), b(Re, d), b(Re, d)
+            S.glane = b(B, nl, lf)
         # gradient at output_fc's output: the head's (or the fusion's) input gradient, first n_out columns
         S.gho = (self.fuse_tape.gin[:, :, :no] if self.map_mode else self.head_tape.gin)
         self.s = S
 
     # ------------------------------------------------------------------ forward
-    def set_batch(self, x_st, y_st, maps=None):
+    def set_batch(self, x_st, y_st, maps=None, lanes=None):
         if tuple(x_st.shape) != tuple(self.x_st.shape) or tuple(y_st.shape) != tuple(self.y_st.shape):
             raise MmtError(f"batch shape {tuple(x_st.shape)} / {tuple(y_st.shape)} does not match the engine's "
                            f"{tuple(self.x_st.shape)} / {tuple(self.y_st.shape)}")
@@ -360,6 +385,10 @@ class TrainEngine:
             if maps is None or tuple(maps.shape) != tuple(self.maps.shape):
                 raise MmtError(f"Map_encoding_CNN training needs maps of shape {tuple(self.maps.shape)}")
             self.maps.copy_(maps)
+        if self.lane_mode:
+            if lanes is None or lanes.numel() != self.lanes.numel():
+                raise MmtError(f"Lane_encoding_CNN training needs lanes of shape {tuple(self.lanes.shape)}")
+            self.lanes.copy_(lanes.reshape(self.lanes.shape))
 
     def forward(self):
         """Encoder -> memory K/V -> ph decoder steps with position feedback; everything the backward needs is kept."""
@@ -379,6 +408,14 @@ class TrainEngine:
             K.gemm(S.ef1[l], _t(lay.linear2.weight), S.etmp, bias=lay.linear2.bias, addend=S.eh1[l])
             K.layernorm_fwd(S.etmp, None, lay.norm2.weight, lay.norm2.bias, S.eh[l + 1], S.exhat2[l], S.erstd2[l])
         memory = S.eh[self.Le]
+        if self.lane_mode:
+            # raw reinterpretation of (B,3,10,2) as (B*3, 2, 10) (mgcvae.py:301-302), then lane 0's feature for every row
+            nl = self.n_lane
+            S.enc_lane = self.lane_tape.forward(self.lanes.view(B * nl, self.lane_emb, 1, self.n_samp)).view(B, nl, -1)
+            S.memcat[:, :d].copy_(memory)
+            S.memcat.view(B, T, -1)[:, :, d:].copy_(S.enc_lane[:, 0:1, :].expand(B, T, -1))
+            self.memfuse_tape.forward_out(self.memfuse_tape.forward_hidden(S.memcat), S.memf)
+            memory = S.memf
         layers = dec.transformer_decoder.layers
         for l, lay in enumerate(layers):
             ca = lay.multihead_attn
@@ -454,11 +491,13 @@ class TrainEngine:
             def dev_sd(m):
                 return {k: v.detach() for k, v in m.state_dict(keep_vars=True).items()}
             self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head),
-                                           dev_sd(self.fuse) if self.map_mode else None)
+                                           dev_sd(self.fuse) if self.map_mode else None,
+                                           dev_sd(self.memfuse) if self.lane_mode else None)
         else:
             self._pdec.repack()
         ops.decoder_forward(self._pdec, S.eh[self.Le].view(self.B, self.T, self.d), S.pad, start_pos=S.pos[0], ph=self.ph,
-                            map_feat=S.enc_map if self.map_mode else None, pred_out=S.pred)
+                            map_feat=S.enc_map if self.map_mode else None,
+                            mem_feat=S.enc_lane[:, 0, :].contiguous() if self.lane_mode else None, pred_out=S.pred)
         S.pos[1:].copy_(S.pred.permute(1, 0, 2))
 
     # ------------------------------------------------------------------ backward
@@ -553,7 +592,7 @@ class TrainEngine:
         R = ph * B
         f2 = lambda t: t.view(R, t.shape[-1])
         self._wgrad(f2(S.gx[0]), f2(S.tok), dec.input_fc.weight, dec.input_fc.bias)
-        memory = S.eh[self.Le]
+        memory = S.memf if self.lane_mode else S.eh[self.Le]          # what the cross-attention K/V were projected from
         for l, lay in enumerate(layers):
             sa, ca = lay.self_attn, lay.multihead_attn
             self._wgrad(f2(S.gqkv[l]), f2(S.x[l]), sa.in_proj_weight, sa.in_proj_bias)
@@ -577,9 +616,17 @@ class TrainEngine:
         else:
             self.head_tape.wgrads(self, f2(S.ho), f2(S.G[1:]))
         # ---- encoder: d memory = sum over decoder layers of d(memory K/V) W_kv
-        gmem = S.geh[self.Le]
+        gmem = S.gmemf if self.lane_mode else S.geh[self.Le]
         for l, lay in enumerate(layers):
             K.gemm(S.gmkv[l], lay.multihead_attn.in_proj_weight[d:], gmem, accumulate=(l > 0))
+        if self.lane_mode:
+            # back through fusion/lane_hist: its input was cat[memory, lane-0 feature repeated over the history]
+            gcat = self.memfuse_tape.backward_step(0, S.gmemf)                     # (B*T, d + lane features)
+            self.memfuse_tape.wgrads(self, S.memcat, S.gmemf)
+            S.geh[self.Le].copy_(gcat[:, :d])
+            S.glane.zero_()
+            torch.sum(gcat.view(B, T, -1)[:, :, d:], dim=1, out=S.glane[:, 0, :])  # lanes 1, 2 never reach the loss (:404)
+            self.lane_tape.backward(self, S.glane.view(B * self.n_lane, -1))
         for l in range(self.Le - 1, -1, -1):
             lay = enc.transformer_encoder.layers[l]
             sa = lay.self_attn
@@ -625,15 +672,15 @@ class _TrainLossFn(torch.autograd.Function):
         return (None,) + tuple(eng.g(p) for _, p in eng.named_params)
 
 
-def train_loss_with_graph(model, x_st, y_st, ph, teacher_forced=False, maps=None):
-    """``MultimodalGenerativeCVAE.train_loss`` body (Basic / Map_encoding_CNN): a scalar that carries autograd."""
+def train_loss_with_graph(model, x_st, y_st, ph, teacher_forced=False, maps=None, lanes=None):
+    """``MultimodalGenerativeCVAE.train_loss`` body (Basic / Map_encoding_CNN / Lane_encoding_CNN): a scalar with autograd."""
     B, T, _ = x_st.shape
     key = (B, T, ph, bool(teacher_forced))
     cache = model.__dict__.setdefault("_train_engines", {})
     eng = cache.get(key)
     if eng is None:
         eng = cache[key] = TrainEngine(model, B, T, ph, teacher_forced=teacher_forced)
-    eng.set_batch(x_st, y_st, maps)
+    eng.set_batch(x_st, y_st, maps, lanes)
     return _TrainLossFn.apply(eng, *[p for _, p in eng.named_params])
 
 
@@ -695,9 +742,9 @@ class Trainer:
         with torch.cuda.graph(self._g_opt):
             self._opt()
 
-    def step(self, x_st, y_st, maps=None):
+    def step(self, x_st, y_st, maps=None, lanes=None):
         """One optimisation step on this rank's shard; returns the local loss as a 1-element device tensor."""
-        self.engine.set_batch(x_st, y_st, maps)
+        self.engine.set_batch(x_st, y_st, maps, lanes)
         if self.use_graph:
             if self._g_fb is None:
                 self._capture()
@@ -714,7 +761,8 @@ class Trainer:
         self.steps_done += 1
         # the kernels wrote the parameters through raw pointers (no torch version bump): drop the packed
         # inference copies so that the next predict() re-packs the updated weights
-        for mod in (self.engine.enc, self.engine.dec, self.engine.head, self.engine.cnn, self.engine.fuse):
+        for mod in (self.engine.enc, self.engine.dec, self.engine.head, self.engine.cnn, self.engine.fuse, self.engine.lane_enc,
+                    self.engine.memfuse):
             if mod is None:
                 continue
             mod.__dict__.pop("_pack_cache", None)

@@ -367,6 +367,43 @@ def test_map_cnn_step_matches_reference(tiny):
             assert ok, (key, e)
 
 
+@pytest.mark.parametrize("tiny", [True, False])
+def test_lane_cnn_step_matches_reference(tiny):
+    """Lane_encoding_CNN training step: lane encoder (Conv1d as im2col + GEMM) and fusion/lane_hist train; tiny config
+    element-wise, full config by norms / first 256 elements / post-AdamW parameters."""
+    from multimodal_transformer_amd import training
+    dev = _dev()
+    z, meta = load_golden("tiny_lane_cnn" if tiny else "full_lane_cnn")
+    hp, B, ph = hp_for("lane_cnn", tiny)
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, tiny, z)
+    batch = batch_for("lane_cnn", tiny)
+    x_st, y_st, lanes = (torch.from_numpy(batch[k]).to(dev) for k in ("x_st", "y_st", "lanes"))
+    tr = training.Trainer(model, B, x_st.shape[1], ph, use_graph=not tiny)
+    loss = tr.step(x_st, y_st, lanes=lanes)
+    assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
+    want = {k for k, v in meta["grad_norms"].items() if v is not None}
+    assert set(tr.engine.grad_by_name) == want
+    for name, g in tr.engine.grad_by_name.items():
+        if tiny:
+            assert rel_err(g.cpu().numpy(), z["grad::" + name]) <= TOL, name
+        else:
+            wn = meta["grad_norms"][name]
+            assert abs(float(g.double().norm()) - wn) <= 1e-3 * wn + 1e-9, name
+            rms = wn / np.sqrt(g.numel())
+            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= 5e-4, name
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            if tiny:
+                ok, e = check_post_step(p.detach().cpu().numpy(), z["post::" + key],
+                                        z["grad::" + key] if "grad::" + key in z.files else None, hp["learning_rate"])
+            else:
+                ok, e = check_post_step(p.detach().reshape(-1)[:256].cpu().numpy(), z["posthead::" + key],
+                                        z["gradhead::" + key] if "gradhead::" + key in z.files else None, hp["learning_rate"])
+            assert ok, (key, e)
+
+
 def test_full_config_step_matches_reference_gradient_norms():
     """BASELINE config 2 per-GPU shard (B=128, T=9, ph=12, 8.0 M parameters): loss, per-parameter gradient norms
     and the post-AdamW weight checksums of the reference."""

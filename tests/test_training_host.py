@@ -85,6 +85,37 @@ def test_map_cnn_forward_backward_and_step_match_reference(monkeypatch):
             assert ok, (key, e)
 
 
+def test_lane_cnn_forward_backward_and_step_match_reference(monkeypatch):
+    """Lane_encoding_CNN as a training configuration: lane encoder (Conv1d + fc) and fusion/lane_hist receive gradients;
+    Lane/MLP_Softmax does not (its output is dead in the reference, mgcvae.py:552-557)."""
+    from multimodal_transformer_amd import training
+    fake_kernels.install(monkeypatch)
+    z, meta = load_golden("tiny_lane_cnn")
+    hp, B, ph = hp_for("lane_cnn", True)
+    model, reg = _model(hp)
+    set_weights(reg.model_dict, True, z)
+    batch = batch_for("lane_cnn", True)
+    x_st, y_st, lanes = (torch.from_numpy(batch[k]) for k in ("x_st", "y_st", "lanes"))
+    tr = training.Trainer(model, x_st.shape[0], x_st.shape[1], ph, use_graph=False)
+    eng = tr.engine
+    eng.set_batch(x_st, y_st, lanes=lanes)
+    loss = eng.forward()
+    assert abs(float(loss) - float(z["train_loss"])) <= 1e-5 * abs(float(z["train_loss"]))
+    eng.backward()
+    want = {k for k, v in meta["grad_norms"].items() if v is not None}
+    assert set(eng.grad_by_name) == want and any("lane_encoder" in k for k in want)
+    for name, g in eng.grad_by_name.items():
+        e = rel_err(g.numpy(), z["grad::" + name])
+        assert e <= GRAD_TOL, (name, e)
+    tr.step(x_st, y_st, lanes=lanes)
+    for name, mod in reg.model_dict.items():
+        for pn, p in mod.named_parameters():
+            key = f"{name}.{pn}"
+            ok, e = check_post_step(p.detach().numpy(), z["post::" + key], z["grad::" + key] if "grad::" + key in z.files
+                                    else None, hp["learning_rate"])
+            assert ok, (key, e)
+
+
 def test_fused_step_matches_reference_adamw(monkeypatch):
     training, model, reg, z, meta, hp, x_st, y_st, ph = _tiny_engine(monkeypatch)
     tr = training.Trainer(model, x_st.shape[0], x_st.shape[1], ph, use_graph=False)
