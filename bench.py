@@ -9,7 +9,7 @@ already resident in HBM.  With N GPUs every rank runs its own batch of 128 (agen
 no data-path collective; weak scaling) and `value` = N*128*K / max-over-ranks time.
 
 The JSON line also carries
-  roofline     for the dominant kernel (the persistent KV-cached decoder): algorithmic FLOPs per launch
+  roofline     for the dominant kernel (the KV-cached autoregressive decoder): algorithmic FLOPs per launch
                (109.91 MFLOP/agent for decoder+head, KV-cached) / its average launch
                duration measured with HIP events on the launch stream, against the dense fp32 MFMA peak;
   cpu_baseline the CPU oracle in reference form (stock torch.nn modules, full recompute per step) timed on
@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also time larger per-GPU batches (extra keys)")
-    ap.add_argument("--decoder", default="auto", choices=["auto", "persistent", "cluster"],
+    ap.add_argument("--decoder", default="auto", choices=["auto", "persistent", "cluster", "cluster_launches"],
                     help="kernel family behind mmt_decoder_forward (include/mmt_amd.h)")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg (extra key 'train')")
     ap.add_argument("--train-steps", type=int, default=30)
@@ -271,14 +271,20 @@ def main():
                         for p in m.parameters())
         dec_bytes = 4.0 * (n_dec_par + B * (args.history + 1) * hp["transformer"]["in_dim"] + B * ph * 2)
         cluster = args.decoder != "persistent" and B <= 512 and args.history + 1 <= 16 and ph <= 16
-        dec_kernel = ("mmt_dec_phase4_kernel / mmt_dec_phase_kernel x%d + mmt_dec_ckv_kernel (cluster decoder)" % (3 * 6 * ph + 1)) if cluster \
-            else "mmt_decoder_kernel (persistent decoder)"
+        fused = cluster and args.decoder != "cluster_launches" and ((B + 3) // 4) * 8 <= 256 and not os.environ.get("MMT_NO_FUSED_DECODER")
+        if fused:
+            dec_kernel = ("mmt_dec_fused4_kernel (all %d phases of the decode in one launch, in-kernel cluster hand-offs) + "
+                          "mmt_dec_ckv_kernel + mmt_dec_phase_kernel (final head)" % (3 * 6 * ph))
+        elif cluster:
+            dec_kernel = "mmt_dec_phase4_kernel / mmt_dec_phase_kernel x%d + mmt_dec_ckv_kernel (cluster decoder)" % (3 * 6 * ph + 1)
+        else:
+            dec_kernel = "mmt_decoder_kernel (persistent decoder)"
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r01", "traffic_b128_basic_v3.json")
-        if cluster and args.mode == "basic" and B == 128 and ph == 12 and args.history == 8 and os.path.exists(tf):
+        tf = os.path.join(ROOT, "profiles", "r01", "traffic_b128_basic_v4.json")
+        if fused and args.mode == "basic" and B == 128 and ph == 12 and args.history == 8 and os.path.exists(tf):
             # HBM-side bytes per decode from separate rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
             traffic = json.load(open(tf))["decoder_bytes_per_predict"]
-            traffic_src = "profiles/r01/traffic_b128_basic_v3.json (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)"
+            traffic_src = "profiles/r01/traffic_b128_basic_v4.json (FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)"
         line = {
             "metric": "predicted agents/sec (12-step, batch 128)",
             "value": value, "unit": "agents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

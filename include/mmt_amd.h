@@ -230,12 +230,20 @@ int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, int B, int T,
 size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph);
 /* Two implementations sit behind mmt_decoder_forward (tuning knob, no counterpart in the reference):
  *   PERSISTENT: one launch, every workgroup owns <= 16 agents and streams all decoder weights each step;
- *   CLUSTER   : 3 short launches per layer per step, 16 agents x nhead workgroups share one sub-layer
- *               (weights split by head / FFN slice, partial sums reduced at the kernel boundary).
- * AUTO (default) picks CLUSTER whenever the geometry allows it (d <= 256, head dim 16/32, d_ff/nhead <= 64). */
+ *   CLUSTER   : RC <= 16 agents x nhead workgroups share one sub-layer (weights split by head / FFN slice, partial
+ *               sums exchanged through memory).  With 4-agent clusters that are all resident at once
+ *               (ceil(B/4)*nhead <= #CUs) the 216 sub-layers of a decode run in ONE launch whose clusters hand their
+ *               partials over in-kernel (write-through stores, an arrival counter per cluster, bounded waits: a
+ *               cluster that cannot complete a wait within 0.2 s makes the call return NaN predictions);
+ *               otherwise 3 short launches per layer per step (the kernel boundary is the exchange).
+ *   CLUSTER_LAUNCHES: AUTO's choice, but never the one-launch form of CLUSTER (also: environment MMT_NO_FUSED_DECODER=1).
+ * AUTO (default) picks CLUSTER whenever the geometry allows it (d <= 256, head dim 16/32, d_ff/nhead <= 64).
+ * The one-launch form assumes it has the GPU's CUs to itself: decodes issued concurrently on several streams still
+ * complete (workgroups are dispatched in order), a GPU shared with other long-running kernels may time out. */
 #define MMT_DECODER_AUTO 0
 #define MMT_DECODER_PERSISTENT 1
 #define MMT_DECODER_CLUSTER 2
+#define MMT_DECODER_CLUSTER_LAUNCHES 3
 int mmt_decoder_select(int impl);
 int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
                         const float *start_pos, const float *map_feat, int map_dim,

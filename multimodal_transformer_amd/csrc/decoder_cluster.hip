@@ -17,12 +17,14 @@
 // whole 128-byte lines and staged in LDS.
 // The head (output_fc, optional map fusion, decoder MLP, position feedback) and the embedding of the next
 // token ride at the front of the next step's first phase A.
+#define MMT_OPAQUE_TID
 #include "mmt_device.cuh"
 #include "mmt_gfx950.cuh"
 
 #include <algorithm>
 #include <cstddef>
 #include <type_traits>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -33,7 +35,7 @@ int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
 #define CLP_LAUNCHES 256
 #define CLP_WGS 64
 __device__ unsigned long long g_clprof[CLP_LAUNCHES][CLP_WGS][8];
-#define CSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < CLP_WGS && a.prof_idx < CLP_LAUNCHES) g_clprof[a.prof_idx][blockIdx.x][k] = wall_clock64(); } while (0)
+#define CSTAMP(k) do { if (thread_idx() == 0 && blockIdx.x < CLP_WGS && a.prof_idx < CLP_LAUNCHES) g_clprof[a.prof_idx][blockIdx.x][k] = wall_clock64(); } while (0)
 extern "C" int mmt_debug_read_clprof(unsigned long long *host, size_t n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clprof), sizeof(unsigned long long) * n);
 }
@@ -73,6 +75,7 @@ struct ClArgs {
   mmt_norm chain_ln[CHAIN_MAX];     // LayerNorm + ReLU after chain[i] when chain_ln[i].g != NULL
   const float *start_pos, *tgt, *map_feat;
   float *pred_st, *h_out;
+  const unsigned *tmo;              // time-out word of the fused kernel (NULL: launch-per-phase path); read by the final head launch
 };
 static_assert(offsetof(ClArgs, input_fc) == 160, "hot block of ClArgs");
 
@@ -103,11 +106,7 @@ __device__ __forceinline__ void ks_load(KsW<SMAX, CPW> &r, const float *Wp, int 
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = w * CPW + i;
-#ifdef EXP_NOW
-      r.w[s][i] = bl4(rs, OOB);
-#else
       r.w[s][i] = bl4(rs, (s < S && c < K16) ? (unsigned)(slab_of(s) * K16 + c) * 1024u + lane_off : OOB);
-#endif
     }
 }
 
@@ -137,7 +136,7 @@ __device__ __forceinline__ void ks_mfma(const KsW<SMAX, CPW> &r, const float *X,
 
 // thread -> output element of reduction pass `it`: idx = tid + CNT*it -> (row, col); col < 16*S when valid
 __device__ __forceinline__ bool ks_elem(int it, int S, int &row, int &col) {
-  const int idx = threadIdx.x + CNT * it;
+  const int idx = thread_idx() + CNT * it;
   const int s = idx >> 8, ln = (idx & 255) >> 2, r = idx & 3;
   row = 4 * (ln >> 4) + r;
   col = s * 16 + (ln & 15);
@@ -149,7 +148,7 @@ __device__ __forceinline__ void ks_reduce(const float *red, int K16, int S, Epi 
   const int nwu = min(CNW, (K16 + CPW - 1) / CPW);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int idx = threadIdx.x + CNT * it;
+    const int idx = thread_idx() + CNT * it;
     if (idx < S * 256) {
       const int s = idx >> 8, rem = idx & 255;
       float sum = 0.f;
@@ -178,11 +177,7 @@ __device__ __forceinline__ void ns_load(NsW<NS_KMAX> &r, const float *Wp, int Kf
 #pragma unroll
     for (int c = 0; c < NS_KMAX; ++c) {
       const int slab = w + CNW * j;
-#ifdef EXP_NOW
-      r.w[j][c] = bl4(rs, OOB);
-#else
       r.w[j][c] = bl4(rs, (slab < D16 && c < K2) ? (unsigned)(slab * Kfull16 + chunk0 + c) * 1024u + lane_off : OOB);
-#endif
     }
 }
 template <int NS_KMAX>
@@ -219,7 +214,7 @@ struct RedRegs {
   f32x4 res[2], bias[2], gam[2], bet[2], p[2][8];
 };
 __device__ __forceinline__ void reduce_issue(RedRegs &R, const ClArgs &a, int cluster) {
-  const int tid = threadIdx.x, row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
+  const int tid = thread_idx(), row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
   const rsrc_t res = mk_rsrc(a.xres_in + (size_t)cluster * 16 * a.d), pp = mk_rsrc(a.part_in + (size_t)cluster * a.H * 16 * a.d);
   const rsrc_t rb = mk_rsrc(a.red_bias), rg = mk_rsrc(a.red_ln.g), rbt = mk_rsrc(a.red_ln.b);
   const unsigned gstride = 16u * a.d * 4u;
@@ -230,18 +225,14 @@ __device__ __forceinline__ void reduce_issue(RedRegs &R, const ClArgs &a, int cl
     const unsigned ro = ok ? (unsigned)(row * a.d + 4 * q) * 4u : OOB, co = ok ? (unsigned)q * 16u : OOB;
     R.res[j] = bl4(res, ro);
 #pragma unroll
-#ifdef EXP_NOPART
-    for (int g = 0; g < 8; ++g) R.p[j][g] = bl4(pp, OOB);
-#else
     for (int g = 0; g < 8; ++g) R.p[j][g] = bl4(pp, (ok && g < a.H) ? g * gstride + ro : OOB);
-#endif
     R.bias[j] = bl4(rb, co);
     R.gam[j] = bl4(rg, co);
     R.bet[j] = bl4(rbt, co);
   }
 }
 __device__ __forceinline__ void reduce_finish(const RedRegs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res) {
-  const int tid = threadIdx.x, row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
+  const int tid = thread_idx(), row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
   const bool live = row < a.RC;
   f32x4 v[2];
   float s = 0.f;
@@ -286,6 +277,7 @@ __device__ __forceinline__ void reduce_finish(const RedRegs &R, const ClArgs &a,
 }
 
 // x = tok W_in^T + b + pe[s]  (Transformer_model.py:100-102); tok is a 16x16 LDS tile (n_in <= 16)
+template <bool SC1 = false>
 __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const float *tok, float *xs, int ldx, bool write_res) {
   const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
   const f32x4 *W4 = reinterpret_cast<const f32x4 *>(a.input_fc.w) + lane;
@@ -301,7 +293,11 @@ __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const 
     for (int rr = 0; rr < 4; ++rr) {
       const float y = acc[rr] + add;
       xs[(row0 + rr) * ldx + col] = y;
-      if (write_res && row0 + rr < a.RC) a.xres_out[((size_t)cluster * 16 + row0 + rr) * a.d + col] = y;
+      if (write_res && row0 + rr < a.RC) {
+        float *dst = a.xres_out + ((size_t)cluster * 16 + row0 + rr) * a.d + col;
+        if constexpr (SC1) __hip_atomic_store((gf32 *)dst, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+        else *dst = y;
+      }
     }
   }
 }
@@ -369,14 +365,14 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
 #pragma unroll
     for (int it = 0; it < DH / 4; ++it) {
       int ag, j, kv, c4;
-      kv_unit<DH>(threadIdx.x + CNT * it, ag, j, kv, c4);
+      kv_unit<DH>(thread_idx() + CNT * it, ag, j, kv, c4);
       M.kv[it] = bl4(rkv, (ag < na && j < nglob) ? (ag * astride + (unsigned)j * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
     }
   }
   M.pad = 0;
   if constexpr (PHASE == PH_B) {
-    const int ar = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && threadIdx.x < 256 && ar < na && l16 < a.T)
+    const int ar = thread_idx() >> 4, l16 = thread_idx() & 15;
+    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && thread_idx() < 256 && ar < na && l16 < a.T)
                                                     ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
   }
   if constexpr (PHASE == PH_C) ns_load(M.w2, a.w2, a.H * a.FS16, g * a.FS16, a.FS16, D16);
@@ -388,9 +384,9 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
 // position feedback; leaves the next token in tok (autoregressive) and pred_st / h_out in global memory (workgroup g == 0).
 template <int CPW>
 __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na, const float *xs, int ldx, float *red, float *ha,
-                                          float *hb, float *tok, const KsW<4, CPW> &wo, KsW<4, 1> sm_cur) {
+                                          float *hb, float *tok, const KsW<4, CPW> &wo, KsW<4, 1> sm_cur, float *pos = nullptr) {
   // head of step hs = s - 1: output_fc -> [fusion/hist_map] -> decoder/MLP -> position feedback (mgcvae.py:435-446)
-  const int hs = a.s - 1, tid = threadIdx.x, K16 = a.d >> 4;
+  const int hs = a.s - 1, tid = thread_idx(), K16 = a.d >> 4;
   __syncthreads();
   const int So = round16(a.n_out) >> 4;
   ks_mfma<4, CPW>(wo, xs, ldx, K16, So, red);
@@ -434,10 +430,14 @@ __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na
     // cur holds delta (n_in columns)
     for (int i = tid; i < na * a.n_in; i += CNT) {
       const int r = i / a.n_in, c = i - r * a.n_in;
+      // previous position: what workgroup 0 of the cluster stored in an earlier LAUNCH, or (fused kernel, where a plain
+      // load of another workgroup's store could be stale) this workgroup's own copy in LDS
       const float prev = hs == 0 ? a.start_pos[(size_t)(a0 + r) * a.n_in + c]
+                         : pos   ? pos[r * 16 + c]
                                  : a.pred_st[((size_t)(a0 + r) * a.ph + hs - 1) * a.n_in + c];
       const float np = prev + cur[r * LDO + c];
       tok[r * LDTOK + c] = np;
+      if (pos) pos[r * 16 + c] = np;
       if (g == 0) a.pred_st[((size_t)(a0 + r) * a.ph + hs) * a.n_in + c] = np;
     }
   }
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   float *Vs = ps + 256;                          // [16][KMAX][LDK]   (phases A, B only)
   float *Ks = red;                               // [16][KMAX][LDK]   reuses the partial-tile region once it is summed
   static_assert(16 * KMAX * LDK <= CNW * KS_SMAX * 256, "K staging must fit the reduction scratch");
-  const int tid = threadIdx.x;
+  const int tid = thread_idx();
   const int G = PHASE == PH_H ? 1 : a.H;
   int cluster, g;
   cluster_of_block(G, cluster, g);
@@ -516,7 +516,17 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   }
   if constexpr (HEAD) {
     head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur);
-    if constexpr (PHASE == PH_H) return;
+    if constexpr (PHASE == PH_H) {
+      // the fused kernel gave up on a wait (a workgroup of a cluster was not resident): fail loudly, never return stale numbers
+      if (a.tmo && __hip_atomic_load((const gu32 *)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __syncthreads();
+        if (a.pred_st)
+          for (int i = tid; i < na * a.ph * a.n_in; i += CNT) a.pred_st[(size_t)a0 * a.ph * a.n_in + i] = __builtin_nanf("");
+        if (a.h_out)
+          for (int i = tid; i < na * a.ph * a.n_out; i += CNT) a.h_out[(size_t)a0 * a.ph * a.n_out + i] = __builtin_nanf("");
+      }
+      return;
+    }
     main_issue<DH, CPW, PHASE>(M, a, a0, na, g);
     __syncthreads();
   }
@@ -674,17 +684,19 @@ struct Red4Regs {
 
 // x = LN(res + bias + sum_g part[g]) for 4 rows: wave w < 4 owns row w, a lane one float4 (d <= 256).  Same summation order
 // over the parts as the 16-row version.
+template <int AUX = AUX_PLAIN>
 __device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int cluster) {
   const int row = wave_id(), q = lane_id();
   const rsrc_t res = mk_rsrc(a.xres_in + ((size_t)cluster * 16 + row) * a.d), pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
   const unsigned co = q < (a.d >> 2) ? (unsigned)q * 16u : OOB, gstride = 16u * a.d * 4u;
-  R.res = bl4(res, co);
+  R.res = bl4x<AUX>(res, co);
 #pragma unroll
-  for (int g = 0; g < 8; ++g) R.p[g] = bl4s(pp, g < a.H ? co : OOB, g < a.H ? g * gstride : 0u);
+  for (int g = 0; g < 8; ++g) R.p[g] = bl4x<AUX>(pp, g < a.H ? co : OOB, g < a.H ? g * gstride : 0u);
   R.bias = bl4(mk_rsrc(a.red_bias), co);
   R.gam = bl4(mk_rsrc(a.red_ln.g), co);
   R.bet = bl4(mk_rsrc(a.red_ln.b), co);
 }
+template <int AUX = AUX_PLAIN>
 __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
@@ -703,11 +715,11 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (acc[e] - mu) * rstd * R.gam[e] + R.bet[e];
     *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = y;
-    if (write_res) reinterpret_cast<f32x4 *>(a.xres_out + ((size_t)cluster * 16 + row) * a.d)[q] = y;
+    if (write_res) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + row) * a.d), (unsigned)q * 16u, y);
   }
 }
 
-template <int DH, int PHASE>
+template <int DH, int PHASE, int AUX = AUX_PLAIN>
 __device__ __forceinline__ void main_issue4(MainRegs4<DH, PHASE> &M, const ClArgs &a, int a0, int na, int g) {
   typedef Geom4<PHASE> G4;
   const int d = a.d, FS = a.FS16 * 16, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
@@ -734,13 +746,13 @@ __device__ __forceinline__ void main_issue4(MainRegs4<DH, PHASE> &M, const ClArg
 #pragma unroll
     for (int it = 0; it < DH / 16; ++it) {
       int ag, jj, kv, c4;
-      kv_unit<DH>(threadIdx.x + CNT * it, ag, jj, kv, c4);
-      M.kv[it] = bl4(rkv, (ag < na && jj < nglob) ? (ag * astride + (unsigned)jj * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+      kv_unit<DH>(thread_idx() + CNT * it, ag, jj, kv, c4);
+      M.kv[it] = bl4x<AUX>(rkv, (ag < na && jj < nglob) ? (ag * astride + (unsigned)jj * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
     }
   }
   M.pad = 0;
   if constexpr (PHASE == PH_B) {
-    const int ar = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int ar = thread_idx() >> 4, l16 = thread_idx() & 15;
     M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && ar < na && l16 < a.T)
                                                     ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
   }
@@ -792,7 +804,7 @@ __device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClA
 }
 
 // part[0..3][d] = x2 W2slice^T (K slice g), straight from the accumulators to global memory
-template <int DH, int PHASE>
+template <int DH, int PHASE, int AUX = AUX_PLAIN>
 __device__ __forceinline__ void gemm2_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *x2, int ld2, float *part) {
   typedef Geom4<PHASE> G4;
   const int d = a.d, K2q = (PHASE == PH_C ? a.FS16 * 16 : DH) / 4, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
@@ -810,18 +822,58 @@ __device__ __forceinline__ void gemm2_4(const MainRegs4<DH, PHASE> &M, const ClA
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = kparts_sum(acc[r], L2.cgw);
-  if (b < L2.cgw) {
-    const int col = (w * L2.cgw + b) * 4 + j;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[r * d + col] = acc[r];
-  }
+  quad_transpose(acc, j);                            // lane j of a quad: row j, the quad's 4 columns -> one 16-byte store
+  bs4x<AUX>(mk_rsrc(part), b < L2.cgw ? (unsigned)(j * d + (w * L2.cgw + b) * 4) * 4u : OOB, acc);
 }
 
-// Phase kernel for clusters of 4 agents (phases A, B, C; the head-only launch stays on mmt_dec_phase_kernel).
-template <int DH, int CPW, int PHASE, int XMODE>
-__global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
+// ---- hand-off between the H workgroups of a cluster INSIDE one launch (fused kernel) -----------------------------------
+// Every byte another workgroup reads (partials, residual rows) is stored write-through (sc1) and loaded past the L1 (sc1);
+// a phase ends with: every wave drains its stores -> workgroup barrier -> ONE lane adds 1 to the cluster's arrival counter;
+// the next phase starts with: ONE lane polls the counter (relaxed, bounded) -> workgroup barrier -> sc1 loads.  The counter
+// only grows (phase p waits for H*p arrivals); it is zeroed by the cross-K/V kernel that runs before.  Correctness does not
+// depend on which XCD a workgroup runs on; cluster_of_block only makes the traffic XCD-local.
+struct FusedSync {
+  gu32 *ctr, *tmo;       // arrival counter of this cluster (a 128-byte line of its own), time-out word of the launch
+  int *abort;            // LDS
+  unsigned phase;        // phases this workgroup has completed
+  int H;
+};
+constexpr unsigned long long FUSED_WAIT_TICKS = 20000000ull;     // 0.2 s of the 100 MHz wall clock: a wait this long = give up
+
+__device__ __forceinline__ bool cluster_wait(const FusedSync &fs) {
+  if (thread_idx() == 0) {
+    const unsigned target = fs.phase * (unsigned)fs.H;
+    if (__hip_atomic_load(fs.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      const unsigned long long t0 = wall_clock64();
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(fs.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        if (wall_clock64() - t0 > FUSED_WAIT_TICKS) {      // a sibling never arrived (not resident, or it gave up): every
+          __hip_atomic_store(fs.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroup reaches this exit
+          *fs.abort = 1;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        // compiler only: no load of handed-off bytes moves above the poll
+  return *fs.abort == 0;
+}
+__device__ __forceinline__ void cluster_arrive(FusedSync &fs) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave, before the barrier
+  __syncthreads();
+  if (thread_idx() == 0) __hip_atomic_fetch_add(fs.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ++fs.phase;
+}
+
+// One phase (A, B or C) of one layer-step for a cluster of 4 agents; the head-only launch stays on mmt_dec_phase_kernel.
+// FUSED: called from the fused kernel's loop - waits for the cluster's previous phase instead of a kernel boundary, stores what
+// other workgroups read write-through and loads it past the L1.
+template <int DH, int CPW, int PHASE, int XMODE, bool FUSED>
+__device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g, float *smem, FusedSync &fs) {
   static_assert(DH == 32 && PHASE != PH_H, "4x4x1 path: 8 column groups per head, one per wave");
-  extern __shared__ __align__(16) float smem[];
+  constexpr int AUX = FUSED ? AUX_SC1 : AUX_PLAIN;
   const int d = a.d, ldx = d + MMT_PAD, K16 = d >> 4;
   constexpr int LD1 = 3 * DH + 8;
   constexpr int LDK = DH + 4;
@@ -835,20 +887,22 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
   float *ps = tok + 16 * LDTOK;                  // [4][16]     attention probabilities
   float *Ks = ps + 256;                          // [4][KMAX][LDK]
   float *Vs = Ks + 4 * KMAX * LDK;               // [4][KMAX][LDK]
-  const int tid = threadIdx.x;
-  int cluster, g;
-  cluster_of_block(a.H, cluster, g);
+  float *pos = ps + 64;                          // [4][16]     fused kernel: the cluster's last positions (ps uses 64 floats)
+  const int tid = thread_idx();
   const int a0 = cluster * 4, na = min(4, a.B - a0);
   constexpr bool HEAD = XMODE == XM_HEAD_EMBED;
   constexpr bool REDUCES = XMODE != XM_EMBED;
   constexpr bool EMBEDS = PHASE == PH_A && XMODE != XM_REDUCE;
 
   CSTAMP(0);
-  hot_args(a);
+  if constexpr (!FUSED) hot_args(a);
   // ---- 1. one burst of requests
+  if constexpr (FUSED && REDUCES) {
+    if (!cluster_wait(fs)) return false;
+  }
   Red4Regs R;
   const bool red_wave = REDUCES && wave_id() < 4;
-  if (red_wave) reduce4_issue(R, a, cluster);
+  if (red_wave) reduce4_issue<AUX>(R, a, cluster);
   MainRegs4<DH, PHASE> M = {};
   KsW<4, CPW> wo = {};
   KsW<4, 1> sm_cur = {};
@@ -856,7 +910,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
     ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });
     if (!a.tgt) small_load(sm_cur, a.chain[0]);
   } else {
-    main_issue4<DH, PHASE>(M, a, a0, na, g);
+    main_issue4<DH, PHASE, AUX>(M, a, a0, na, g);
   }
   CSTAMP(1);
   if constexpr (EMBEDS) {                          // the head's 16-row tiles and the token tile must be finite
@@ -868,10 +922,10 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
   }
 
   // ---- 2. input of this sub-layer
-  if (red_wave) reduce4_finish(R, a, cluster, xs, ldx, g == 0 && !HEAD);
+  if (red_wave) reduce4_finish<AUX>(R, a, cluster, xs, ldx, g == 0 && !HEAD);
   if constexpr (HEAD) {
-    head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur);
-    main_issue4<DH, PHASE>(M, a, a0, na, g);
+    head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur, FUSED ? pos : nullptr);
+    main_issue4<DH, PHASE, AUX>(M, a, a0, na, g);
     __syncthreads();
   }
   if constexpr (EMBEDS) {
@@ -882,7 +936,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
                                    : a.start_pos[(size_t)(a0 + r) * a.n_in + c];
       }
     __syncthreads();
-    embed_token(a, cluster, tok, xs, ldx, g == 0);
+    embed_token<FUSED>(a, cluster, tok, xs, ldx, g == 0);
   }
   __syncthreads();
   CSTAMP(2);
@@ -951,8 +1005,8 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
       }
 #pragma unroll
       for (int e = 0; e < DPL; ++e) ob[ar * LDO + l16 * DPL + e] = o[e];
-    } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read by later launches)
-      const int i = tid - 256;
+    } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read by later launches /
+      const int i = tid - 256;                       // later phases of this same workgroup only)
       if (i < na * 2 * (DH / 4)) {
         const int r = i / (2 * (DH / 4)), rem = i - r * 2 * (DH / 4), kv = rem / (DH / 4), c4 = rem - kv * (DH / 4);
         *reinterpret_cast<f32x4 *>(a.kv + (((size_t)a.L * a.B + a0 + r) * a.ph + a.s) * 2 * d + kv * d + g * DH + 4 * c4) =
@@ -966,8 +1020,108 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
   CSTAMP(4);
 
   // ---- 5. K-slice of the output projection: partial [4][d] of this workgroup
-  gemm2_4<DH, PHASE>(M, a, x2, ld2, a.part_out + ((size_t)cluster * a.H + g) * 16 * d);
+  gemm2_4<DH, PHASE, AUX>(M, a, x2, ld2, a.part_out + ((size_t)cluster * a.H + g) * 16 * d);
   CSTAMP(5);
+  if constexpr (FUSED) {
+    cluster_arrive(fs);
+    CSTAMP(6);
+  }
+  return true;
+}
+
+template <int DH, int CPW, int PHASE, int XMODE>
+__global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  int cluster, g;
+  cluster_of_block(a.H, cluster, g);
+  FusedSync fs = {};
+  phase4_body<DH, CPW, PHASE, XMODE, false>(a, cluster, g, smem, fs);
+}
+
+// ------------------------------------------------------------------------------- fused kernel: every phase of a decode in ONE launch
+// When all clusters are resident at once (4-agent clusters: ceil(B/4)*H workgroups <= #CUs, one per CU) the 216 kernel
+// boundaries of a decode become 216 cluster-level hand-offs: the H workgroups of a cluster wait only for each other.  The final
+// head (PH_H) stays a launch of its own.  Measured at B = 128: 1.22 ms against 1.42 ms for the launch-per-phase form.
+// Requesting the next phase's weights early (behind the arrival, or under the attention of the phase before) was measured and
+// is SLOWER (1.31 / 1.38 ms): loads return in order, so the partials - the critical path - queue behind 128 KB of weights, and
+// the drain that precedes an arrival waits for everything in flight.
+struct FusedLayer {
+  const float *w1[3], *b1[3], *w2[3];          // phases A, B, C: first linear (+ bias), second linear (4x4x1 order)
+  const float *red_bias[3];                    // what a phase's prologue adds and normalises with (phase A: the previous layer's
+  mmt_norm red_ln[3];                          //   linear2 bias / norm3 - filled in per layer by the host, layer 0: the last layer's)
+};
+struct FusedArgs {
+  ClArgs a;
+  FusedLayer layer[MMT_MAX_LAYERS];
+  float *part[2], *xres[2], *selfkv, *memkv;
+  unsigned *sync;                              // [0]: time-out word; [32 * (1 + cluster)]: arrival counter
+  int nlayers;
+};
+
+// the per-phase fields of the argument block; everything else stays as the host filled it in
+template <int PHASE>
+__device__ __forceinline__ void fused_set_phase(ClArgs &x, const FusedArgs &f, int s, int l, unsigned p) {
+  const FusedLayer &W = f.layer[l];
+  // (scalars too: re-read per phase through an empty volatile asm, or everything derived from them is hoisted out of the loop
+  // and spilled)
+  auto fresh = [](int v) { asm volatile("" : "+s"(v)); return v; };
+  x.d = fresh(f.a.d);
+  x.B = fresh(f.a.B);
+  x.T = fresh(f.a.T);
+  x.H = fresh(f.a.H);
+  x.ph = fresh(f.a.ph);
+  x.FS16 = fresh(f.a.FS16);
+  x.s = s;
+  x.L = l;
+  x.w1 = W.w1[PHASE];
+  x.b1 = W.b1[PHASE];
+  x.w2 = W.w2[PHASE];
+  x.red_bias = W.red_bias[PHASE];
+  x.red_ln = W.red_ln[PHASE];
+  x.kv = PHASE == PH_A ? f.selfkv : f.memkv;
+  x.part_out = f.part[p & 1];
+  x.xres_out = f.xres[p & 1];
+  x.part_in = f.part[(p + 1) & 1];
+  x.xres_in = f.xres[(p + 1) & 1];
+  x.prof_idx = (int)p;
+}
+
+template <int DH, int CPW>
+__global__ __launch_bounds__(CNT) void mmt_dec_fused4_kernel(FusedArgs f) {
+  extern __shared__ __align__(16) float smem[];
+  // (XCD-local clusters matter here too although the partials are stored write-through: with slice g on XCD g % 8 instead - an
+  // XCD's L2 would then keep its 1/8 of the weights for the whole decode - the decode took 1.32 ms instead of 1.22 ms)
+  int cluster, g;
+  cluster_of_block(f.a.H, cluster, g);
+  const int L = f.nlayers, ph = f.a.ph;
+  constexpr int LD1 = 3 * DH + 8;
+  float *ps = smem + 16 * (f.a.d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK;
+  FusedSync fs;
+  fs.ctr = (gu32 *)(f.sync + 32 * (1 + cluster));
+  fs.tmo = (gu32 *)f.sync;
+  fs.abort = reinterpret_cast<int *>(ps + 128);
+  fs.phase = 0;
+  fs.H = f.a.H;
+  if (thread_idx() == 0) *fs.abort = 0;             // read only behind a workgroup barrier
+  ClArgs a = f.a;
+  unsigned p = 0;
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < ph; ++s) {
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < L; ++l) {
+      fused_set_phase<PH_A>(a, f, s, l, p);
+      bool ok;
+      if (l > 0) ok = phase4_body<DH, CPW, PH_A, XM_REDUCE, true>(a, cluster, g, smem, fs);
+      else if (s == 0) ok = phase4_body<DH, CPW, PH_A, XM_EMBED, true>(a, cluster, g, smem, fs);
+      else ok = phase4_body<DH, CPW, PH_A, XM_HEAD_EMBED, true>(a, cluster, g, smem, fs);
+      if (!ok) return;
+      fused_set_phase<PH_B>(a, f, s, l, p + 1);
+      if (!phase4_body<DH, CPW, PH_B, XM_REDUCE, true>(a, cluster, g, smem, fs)) return;
+      fused_set_phase<PH_C>(a, f, s, l, p + 2);
+      if (!phase4_body<DH, CPW, PH_C, XM_REDUCE, true>(a, cluster, g, smem, fs)) return;
+      p += 3;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------- prologue kernels
@@ -975,14 +1129,18 @@ struct CkvArgs {
   int rows, d, L, B, T, ldx, ldb;
   const float *src;          // (rows, d): memory or fused memory
   float *memkv;              // [L][rows][2d]
+  unsigned *sync;            // fused kernel's time-out word + arrival counters: zeroed here, one launch ahead of their use
+  int nsync;
   mmt_linear ckv[MMT_MAX_LAYERS];
 };
 // cross-attention K/V of every layer (computed once per decode; the reference redoes it every step)
 __global__ __launch_bounds__(CNT) void mmt_dec_ckv_kernel(CkvArgs a) {
   extern __shared__ __align__(16) float smem[];
   float *xs = smem, *buf = xs + 16 * a.ldx;
-  const int tid = threadIdx.x, d = a.d, L = blockIdx.y;
+  const int tid = thread_idx(), d = a.d, L = blockIdx.y;
   const int r0 = blockIdx.x * 16, nr = min(16, a.rows - r0);
+  if (blockIdx.x == 0 && L == 0)
+    for (int i = tid; i < a.nsync; i += CNT) a.sync[i] = 0u;
   for (int i = tid; i < 16 * (a.ldx + a.ldb); i += CNT) smem[i] = 0.f;
   __syncthreads();
   for (int i = tid; i < nr * (d >> 2); i += CNT) {
@@ -1009,7 +1167,7 @@ struct FuseArgs {
 __global__ __launch_bounds__(CNT) void mmt_dec_fuse_kernel(FuseArgs a) {
   extern __shared__ __align__(16) float smem[];
   float *ra = smem, *rb = ra + 16 * a.ld, *out = rb + 16 * a.ld;
-  const int tid = threadIdx.x, d = a.d, mf = a.mf;
+  const int tid = thread_idx(), d = a.d, mf = a.mf;
   const int r0 = blockIdx.x * 16, nr = min(16, a.rows - r0);
   for (int i = tid; i < 16 * 3 * a.ld; i += CNT) smem[i] = 0.f;
   __syncthreads();
@@ -1078,7 +1236,7 @@ __device__ __forceinline__ float lin4_first_elem(const float *__restrict__ w, in
 }
 __global__ void mmt_pack_lin4_first_kernel(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
                                            size_t total, float *__restrict__ dst) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + thread_idx();
   if (i < total) dst[i] = lin4_first_elem(w, ldw, nparts, part_rows, slice_rows, k, i);
 }
 __device__ __forceinline__ float lin4_second_elem(const float *__restrict__ w, int ldw, int n, int slice_k, size_t i) {
@@ -1092,14 +1250,14 @@ __device__ __forceinline__ float lin4_second_elem(const float *__restrict__ w, i
 }
 __global__ void mmt_pack_lin4_second_kernel(const float *__restrict__ w, int ldw, int n, int slice_k, size_t total,
                                             float *__restrict__ dst) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + thread_idx();
   if (i < total) dst[i] = lin4_second_elem(w, ldw, n, slice_k, i);
 }
 // every re-layout of a module in one launch: blockIdx.y = job
 __global__ __launch_bounds__(256) void mmt_pack_jobs_kernel(const mmt_pack_job *__restrict__ table) {
   const mmt_pack_job J = table[blockIdx.y];
   const size_t total = (size_t)J.total;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + thread_idx(); i < total; i += (size_t)gridDim.x * blockDim.x) {
     float v;
     if (J.kind == 0) {
       v = J.src[i];
@@ -1175,7 +1333,8 @@ bool mmt_cluster_decoder_supports(const mmt_decoder *dec, int map_dim, bool auto
 size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
   const int RC = cluster_rows(B, dec->nhead);
   const size_t NC = (B + RC - 1) / RC, d = dec->d_model;
-  return NC * 16 * d * (2 * (size_t)dec->nhead + 2) + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64;
+  // + the fused kernel's time-out word and per-cluster arrival counters, one 128-byte line each (32 floats of slack to align them)
+  return NC * 16 * d * (2 * (size_t)dec->nhead + 2) + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64 + (NC + 2) * 32;
 }
 
 #define CL_CHECK(what)                                                                     \
@@ -1186,7 +1345,7 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
 
 template <int DH, int CPW, bool M4>
 static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], float *memkv, float *selfkv,
-                         hipStream_t st) {
+                         unsigned *sync, bool fused, hipStream_t st) {
   const int d = dec->d_model, H = dec->nhead, NC = (B + a.RC - 1) / a.RC, L = dec->nlayers;
   constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
   const size_t lds_c = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256) * sizeof(float);
@@ -1207,6 +1366,8 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
     SET_LDS(PH_C, XM_REDUCE, lds_c);
     SET_LDS(PH_H, XM_REDUCE, lds_c);
 #undef SET_LDS
+    if constexpr (M4)
+      (void)hipFuncSetAttribute((const void *)mmt_dec_fused4_kernel<DH, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
     attr_done = true;
   }
 #define LAUNCH_PHASE(PHASE, XM, BYTES)                                                                     \
@@ -1225,7 +1386,30 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   };
   const mmt_dec_layer &last = dec->layer[L - 1];
   const dim3 grid(NC * H), blk(CNT);
-  for (int s = 0; s < ph; ++s) {
+  if constexpr (M4) {
+    if (fused) {
+      FusedArgs f;
+      memset(&f, 0, sizeof(f));
+      f.a = a;
+      for (int l = 0; l < L; ++l) {
+        const mmt_dec_layer &W = dec->layer[l];
+        const mmt_dec_layer &prev = l == 0 ? last : dec->layer[l - 1];
+        FusedLayer &F = f.layer[l];
+        F.w1[PH_A] = W.qkv4, F.b1[PH_A] = W.qkv.b, F.w2[PH_A] = W.out4, F.red_bias[PH_A] = prev.ff2.b, F.red_ln[PH_A] = prev.ln3;
+        F.w1[PH_B] = W.cq4, F.b1[PH_B] = W.cq.b, F.w2[PH_B] = W.cout4, F.red_bias[PH_B] = W.out.b, F.red_ln[PH_B] = W.ln1;
+        F.w1[PH_C] = W.ff14, F.b1[PH_C] = W.ff1.b, F.w2[PH_C] = W.ff24, F.red_bias[PH_C] = W.cout.b, F.red_ln[PH_C] = W.ln2;
+      }
+      for (int i = 0; i < 2; ++i) f.part[i] = part[i], f.xres[i] = xres[i];
+      f.selfkv = selfkv;
+      f.memkv = memkv;
+      f.sync = sync;
+      f.nlayers = L;
+      hipLaunchKernelGGL((mmt_dec_fused4_kernel<DH, CPW>), grid, blk, lds_a, st, f);
+      p = 3 * L * ph;
+      a.tmo = sync;
+    }
+  }
+  for (int s = 0; s < (fused ? 0 : ph); ++s) {
     a.s = s;
     for (int l = 0; l < L; ++l) {
       a.L = l;
@@ -1272,7 +1456,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                void *stream) {
+                                bool allow_fused, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d_model, H = dec->nhead, L = dec->nlayers;
   const int RC = cluster_rows(B, H), NC = (B + RC - 1) / RC;
@@ -1285,6 +1469,15 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   xres[0] = part[1] + (size_t)NC * H * 16 * d;
   xres[1] = xres[0] + (size_t)NC * 16 * d;
   float *fused = xres[1] + (size_t)NC * 16 * d;
+  float *after = fused + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64;
+  unsigned *sync = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(after) + 127) & ~(uintptr_t)127);
+  // One launch for all phases when every workgroup of the decode is resident at once (one per CU: the phase kernels need
+  // > 80 KB of LDS) and the 4x4x1 path applies; else a launch per phase.  MMT_NO_FUSED_DECODER=1 forces the latter.
+  int dev = 0, ncu = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const bool m4 = RC == 4 && mfma4_fits(dec);
+  const bool fuse_phases = allow_fused && m4 && NC * H <= ncu && !getenv("MMT_NO_FUSED_DECODER");
 
   const float *src = memory;
   const int rows = B * T;
@@ -1317,6 +1510,8 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
     c.ldb = 2 * d + MMT_PAD;
     c.src = src;
     c.memkv = memkv;
+    c.sync = sync;
+    c.nsync = fuse_phases ? (NC + 1) * 32 : 0;
     for (int l = 0; l < L; ++l) c.ckv[l] = dec->layer[l].ckv;
     const size_t lds = (size_t)16 * (c.ldx + c.ldb) * sizeof(float);
     hipLaunchKernelGGL(mmt_dec_ckv_kernel, dim3((rows + 15) / 16, L), dim3(CNT), lds, st, c);
@@ -1357,10 +1552,14 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   a.pad_mask = pad_mask;
   const int dh = d / H;
   const bool cpw2 = d > 128;
-  if (RC == 4 && mfma4_fits(dec)) {
+  if (m4) {
     // (CPW still sizes the K-split of the head's small linears, which stay on 16x16x4 tiles)
-    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, st);
+    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, fuse_phases, st)
+                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, fuse_phases, st);
   }
-  if (dh == 32) return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, st);
-  return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, st) : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, st);
+  if (dh == 32)
+    return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st)
+                : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st);
+  return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st)
+              : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st);
 }

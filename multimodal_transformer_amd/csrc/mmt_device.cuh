@@ -15,8 +15,18 @@
 #define MMT_LN_EPS 1e-5f
 #define MMT_PAD 8   // row padding (floats) that makes the ds_read_b128 A-operand reads conflict free
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // SGPR: keeps wave-level control flow scalar
+// MMT_OPAQUE_TID (decoder_cluster.hip): the thread index goes through an empty volatile asm, so that nothing derived from it is
+// loop invariant.  The fused decoder kernel inlines five phase bodies into one loop; left alone, LICM hoists every per-lane
+// offset of every body into the loop preheader and the kernel spills hundreds of registers.
+__device__ __forceinline__ int thread_idx() {
+  int t = threadIdx.x;
+#ifdef MMT_OPAQUE_TID
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
+__device__ __forceinline__ int lane_id() { return thread_idx() & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(thread_idx() >> 6); }   // SGPR: keeps wave-level control flow scalar
 __device__ __forceinline__ int n_waves() { return blockDim.x >> 6; }
 
 __device__ __forceinline__ int round16(int v) { return (v + 15) & ~15; }

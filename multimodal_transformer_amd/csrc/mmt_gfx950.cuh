@@ -20,6 +20,20 @@ __device__ __forceinline__ f32x4 bl4(rsrc_t r, unsigned byte_off) {
 __device__ __forceinline__ f32x4 bl4s(rsrc_t r, unsigned byte_off, unsigned uniform_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, uniform_off, 0));
 }
+// cache-policy forms for data that workgroups hand to each other inside one launch: AUX_SC1 stores write through to
+// memory, AUX_SC1 loads bypass this CU's L1 (which no other CU's store ever refreshes)
+constexpr int AUX_PLAIN = 0, AUX_SC1 = 16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int AUX>
+__device__ __forceinline__ f32x4 bl4x(rsrc_t r, unsigned byte_off, unsigned uniform_off = 0u) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, uniform_off, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void bs4x(rsrc_t r, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, AUX);
+}
+typedef __attribute__((address_space(1))) unsigned gu32;      // global (never flat) words that workgroups poll / raise
+typedef __attribute__((address_space(1))) float gf32;
 __device__ __forceinline__ float bl1(rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
@@ -60,3 +74,12 @@ __device__ __forceinline__ float xor32_sum(float v) {
   return a + b;
 }
 __device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+
+// 4x4 transpose inside every quad of lanes: lane j's register r  <->  lane r's register j
+__device__ __forceinline__ void quad_transpose(f32x4 &a, int j) {
+  float s, r;
+  s = (j & 1) ? a[0] : a[1]; r = dpp_mov<0xB1>(s); if (j & 1) a[0] = r; else a[1] = r;
+  s = (j & 1) ? a[2] : a[3]; r = dpp_mov<0xB1>(s); if (j & 1) a[2] = r; else a[3] = r;
+  s = (j & 2) ? a[0] : a[2]; r = dpp_mov<0x4E>(s); if (j & 2) a[0] = r; else a[2] = r;
+  s = (j & 2) ? a[1] : a[3]; r = dpp_mov<0x4E>(s); if (j & 2) a[1] = r; else a[3] = r;
+}

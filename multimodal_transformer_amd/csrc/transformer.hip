@@ -470,11 +470,11 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T);
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                void *stream);
+                                bool allow_fused, void *stream);
 
 static int g_decoder_impl = MMT_DECODER_AUTO;
 extern "C" int mmt_decoder_select(int impl) {
-  if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER)
+  if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_LAUNCHES)
     return fail(MMT_EINVAL, "mmt_decoder_select: unknown implementation %d", impl);
   g_decoder_impl = impl;
   return MMT_OK;
@@ -523,7 +523,7 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   // AUTO: the cluster kernels win while one cluster round fits the chip (16 agents x nhead workgroups each, <= #CUs
   // workgroups: B <= 512 at 8 heads on MI355X); beyond that the persistent kernel's larger tiles are faster.
   bool use_cluster = cluster_ok && g_decoder_impl != MMT_DECODER_PERSISTENT;
-  if (use_cluster && g_decoder_impl == MMT_DECODER_AUTO) {
+  if (use_cluster && g_decoder_impl != MMT_DECODER_CLUSTER) {
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -531,7 +531,7 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   }
   if (use_cluster)
     return mmt_cluster_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T,
-                                       ph, pred_st, h_out, workspace, stream);
+                                       ph, pred_st, h_out, workspace, g_decoder_impl != MMT_DECODER_CLUSTER_LAUNCHES, stream);
   // buf = [ region A | region B ], region B additionally split in two for the map-fusion ping-pong
   const int half = std::max((3 * d + 1) / 2, 2 * (small + MMT_PAD));
   const int halfr = (half + 15) & ~15;

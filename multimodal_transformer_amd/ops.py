@@ -485,8 +485,10 @@ def encoder_forward(enc: PackedEncoder, x_st: torch.Tensor, want_mask: bool = Tr
 
 
 def decoder_select(impl: str = "auto"):
-    """Choose the kernel family behind ``decoder_forward``: "auto" | "persistent" | "cluster" (include/mmt_amd.h)."""
-    table = {"auto": _lib.MMT_DECODER_AUTO, "persistent": _lib.MMT_DECODER_PERSISTENT, "cluster": _lib.MMT_DECODER_CLUSTER}
+    """Choose the kernel family behind ``decoder_forward``: "auto" | "persistent" | "cluster" | "cluster_launches"
+    (include/mmt_amd.h)."""
+    table = {"auto": _lib.MMT_DECODER_AUTO, "persistent": _lib.MMT_DECODER_PERSISTENT, "cluster": _lib.MMT_DECODER_CLUSTER,
+             "cluster_launches": _lib.MMT_DECODER_CLUSTER_LAUNCHES}
     if impl not in table:
         raise MmtError(f"decoder_select: unknown implementation {impl!r}")
     _lib.check(_lib.load().mmt_decoder_select(table[impl]), "mmt_decoder_select")

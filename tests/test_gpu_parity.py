@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(autouse=True, params=["auto", "persistent"])
+@pytest.fixture(autouse=True, params=["auto", "persistent", "cluster_launches"])
 def decoder_impl(request):
     """Every test runs on both decoder kernel families (include/mmt_amd.h: mmt_decoder_select): "auto" takes the
     cluster kernels wherever their geometry allows (d <= 256, <= 16 keys), "persistent" forces the one-launch kernel."""
@@ -189,6 +189,45 @@ def test_batch_invariance_and_determinism():
     assert torch.equal(full, torch.cat(parts))
     odd = model.predict(x[:37].contiguous(), x_st[:37].contiguous(), None, None, None, 12)[0]
     assert torch.equal(full[:37], odd)
+
+
+def _flat(out):
+    """tensors of a predict() result (a tensor, None, or nested lists / tuples of them)"""
+    if out is None:
+        return []
+    if torch.is_tensor(out):
+        return [out]
+    return [t for o in out for t in _flat(o)]
+
+
+def test_fused_decoder_is_bit_identical_to_launch_per_phase():
+    """The one-launch cluster decoder (in-kernel hand-offs between the workgroups of a cluster) runs the same arithmetic in the
+    same order as the launch-per-phase form: outputs must be bit-identical, call after call, for full and ragged cluster
+    counts, in all three modes, also with other work queued on a second stream (a stale read of a handed-off partial would
+    show up as a difference)."""
+    from multimodal_transformer_amd import ops
+    dev = _dev()
+    side = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    other = torch.cuda.Stream()
+    for mode in ("basic", "map_cnn", "lane_cnn"):
+        hp = make_hyperparams(mode, history=8, horizon=12)
+        model, reg = _model(hp, dev)
+        apply_recipe(reg.model_dict, seed=0)
+        for B in (128, 37, 3):
+            x, x_st, _, _, lanes, maps = _to(make_batch(B, 8, 12, seed=B, with_map=(mode == "map_cnn"),
+                                                        with_lanes=(mode == "lane_cnn")), dev)
+            ops.decoder_select("cluster_launches")
+            want = model.predict(x, x_st, lanes, None, maps, 12)
+            ops.decoder_select("cluster")
+            for it in range(8):
+                if it % 2:
+                    with torch.cuda.stream(other):
+                        side.add_(1.0)                     # streams through the caches beside the decode
+                got = model.predict(x, x_st, lanes, None, maps, 12)
+                for w, g_ in zip(_flat(want), _flat(got)):
+                    assert torch.isfinite(g_).all()
+                    assert torch.equal(w, g_), (mode, B, it)
+            torch.cuda.synchronize()
 
 
 def test_large_batch_properties():

@@ -41,3 +41,15 @@ for p in range(60, 60 + 3 * 8):          # a few layers in the middle of the dec
           " ".join(f"{nm}={v:5.2f}" for nm, v in zip(names, stages)) + f" | span={(end.max() - start.min()) / 100.0:6.2f}")
     prev_end = end.max()
 
+
+if st[61, 0, 6] > 0:      # the one-launch form stamps the arrival too
+    print("fused kernel: per-phase stage means over the first %d workgroups (us)" % nwg)
+    names = ["wait+issue", "LN(+head)", "gemm1", "attn", "gemm2", "drain+arrive"]
+    tot = np.zeros(7)
+    for p in range(36, 36 + 18):
+        w = st[p, :nwg]
+        stages = [(w[:, k + 1] - w[:, k]).mean() / 100.0 for k in range(6)]
+        nxt = (st[p + 1, :nwg, 0] - w[:, 6]).mean() / 100.0
+        tot += np.array(stages + [nxt])
+        print(f"{p:4d} {'ABC'[p % 3]} " + " ".join(f"{nm}={v:5.2f}" for nm, v in zip(names, stages)) + f" next={nxt:5.2f} | phase={(st[p + 1, :nwg, 0] - w[:, 0]).mean() / 100.0:5.2f}")
+    print("mean per phase:", " ".join(f"{nm}={v / 18:5.2f}" for nm, v in zip(names + ["next"], tot)), f"sum={tot.sum() / 18:5.2f}")
