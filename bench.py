@@ -253,10 +253,10 @@ def main():
     assert torch.isfinite(res).all()
 
     train = None
-    if args.mode in ("basic", "map_cnn", "lane_cnn") and not args.no_train:       # every rank takes part (all-reduce inside)
+    if not args.no_train:       # every rank takes part (all-reduce inside)
         try:
             train = bench_train(model, hp, dev, B, args.history, ph, rank, world, args.train_steps,
-                                max(3, min(args.warmup, 5)), dist if distributed else None, with_map=(args.mode == "map_cnn"),
+                                max(3, min(args.warmup, 5)), dist if distributed else None, with_map=(args.mode in ("map_cnn", "map_vit")),
                                 with_lanes=(args.mode == "lane_cnn"))
         except Exception as e:       # the headline metric must survive a failure of the extra leg
             train = {"error": f"{type(e).__name__}: {e}"}

@@ -324,6 +324,17 @@ int mmt_cumsum_axis(const float *x, long outer, int n, long inner, float *y, voi
 /* y += x (gradient of that cumsum walked backwards in time) */
 int mmt_add_inplace(float *y, const float *x, long n, void *stream);
 
+/* ---- ViT map encoder, training pieces (third-party vit_pytorch==0.33.2, call sites mgcvae.py:17,145-155,294-296) ----
+ * patch rearrange 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' of alpha*img+beta: img (B,C,S,S) -> out (B*(S/P)^2 rows, ld floats apart) */
+int mmt_patchify(const float *img, int B, int C, int S, int P, float alpha, float beta, float *out, long ld, void *stream);
+/* nn.GELU (exact, erf form) and its derivative: dz = dy * gelu'(z) */
+int mmt_gelu_fwd(const float *z, float *y, long n, void *stream);
+int mmt_gelu_bwd(const float *z, const float *dy, float *dz, long n, void *stream);
+/* dst[b][r][0..N) (+)= src[b][r][0..N) for views with batch / row strides in floats (a source stride of 0 broadcasts):
+ * cls / position token assembly, cls pooling and their gradients */
+int mmt_copy3(const float *src, long sbs, long srs, float *dst, long dbs, long drs, int B, int R, int N, int accumulate,
+              void *stream);
+
 /* ---- GMM2D (Transformer/model/components/gmm2d.py:7-217; dead code in the live path, named by the north star) ----
  * R = product of the leading dims, N = components (<= 64); mus / log_sigmas / sigmas (R,N,2), corrs & co (R,N).
  * prepare = __init__ (:39-66): normalised log_pis, sigmas, clamp(1-rho^2), Cholesky L (R,N,2,2), covariance (:211-217);

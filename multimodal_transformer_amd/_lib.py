@@ -151,6 +151,10 @@ SIGNATURES = {
     "mmt_softmax_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
     "mmt_cumsum_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
     "mmt_add_inplace": (C.c_int, [fptr, fptr, C.c_long, C.c_void_p]),
+    "mmt_patchify": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, fptr, C.c_long, C.c_void_p]),
+    "mmt_gelu_fwd": (C.c_int, [fptr, fptr, C.c_long, C.c_void_p]),
+    "mmt_gelu_bwd": (C.c_int, [fptr, fptr, fptr, C.c_long, C.c_void_p]),
+    "mmt_copy3": (C.c_int, [fptr, C.c_long, C.c_long, fptr, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mmt_gmm2d_prepare": (C.c_int, [fptr, fptr, fptr, C.c_long, C.c_int, fptr, fptr, fptr, fptr, fptr, C.c_void_p]),
     "mmt_gmm2d_log_prob": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, fptr, C.c_long, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_gmm2d_rsample": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_long, C.c_long, C.c_int, fptr, fptr, C.c_void_p]),

@@ -373,3 +373,39 @@ def add_inplace(y, x):
     _contig2(y, "y", y.shape), _contig2(x, "x", y.shape)
     lib = _lib.load()
     _lib.check(lib.mmt_add_inplace(_p(y), _p(x), y.numel(), _stream()), "mmt_add_inplace")
+
+
+def patchify(img, patch, out, alpha=1.0, beta=0.0):
+    """out rows (b, hy, wx) = the (p1 p2 c)-ordered pixels of patch (hy, wx) of alpha*img+beta; img (B,C,S,S) contiguous, out a
+    (B*(S/P)^2, P*P*C) view with unit column stride."""
+    _contig2(img, "img")
+    B, Cc, S, S2 = img.shape
+    _dev(out, "out")
+    if S != S2 or S % patch or tuple(out.shape) != (B * (S // patch) ** 2, patch * patch * Cc) or out.stride(1) != 1:
+        raise MmtError(f"patchify: img {tuple(img.shape)} / out {tuple(out.shape)} do not fit patch {patch}")
+    lib = _lib.load()
+    _lib.check(lib.mmt_patchify(_p(img), B, Cc, S, int(patch), float(alpha), float(beta), _p(out), out.stride(0), _stream()),
+               "mmt_patchify")
+
+
+def gelu_fwd(z, y):
+    _contig2(z, "z"), _contig2(y, "y", z.shape)
+    lib = _lib.load()
+    _lib.check(lib.mmt_gelu_fwd(_p(z), _p(y), z.numel(), _stream()), "mmt_gelu_fwd")
+
+
+def gelu_bwd(z, dy, dz):
+    _contig2(z, "z"), _contig2(dy, "dy", z.shape), _contig2(dz, "dz", z.shape)
+    lib = _lib.load()
+    _lib.check(lib.mmt_gelu_bwd(_p(z), _p(dy), _p(dz), z.numel(), _stream()), "mmt_gelu_bwd")
+
+
+def copy3(src, dst, accumulate=False):
+    """dst (+)= src for (B,R,N) views with unit column stride; src may be an expand()ed (stride-0) view."""
+    _dev(src, "src"), _dev(dst, "dst")
+    if src.dim() != 3 or tuple(src.shape) != tuple(dst.shape) or src.stride(2) != 1 or dst.stride(2) != 1:
+        raise MmtError(f"copy3: need equal (B,R,N) views with unit column stride, got {tuple(src.shape)} {tuple(dst.shape)}")
+    B, R, N = src.shape
+    lib = _lib.load()
+    _lib.check(lib.mmt_copy3(_p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), B, R, N,
+                             int(bool(accumulate)), _stream()), "mmt_copy3")

@@ -998,6 +998,48 @@ __global__ void mmt_add_inplace_kernel(float *__restrict__ y, const float *__res
   if (i < n) y[i] += x[i];
 }
 
+// ---- ViT map encoder training pieces (vit_pytorch 0.33.2: patch rearrange, nn.GELU, cls / position tokens) ----
+// img (B,C,S,S) -> patches (B*(S/P)^2, ld): row (b, hy, wx), column (p1*P + p2)*C + c   ('b c (h p1) (w p2) -> b (h w) (p1 p2 c)')
+__global__ void mmt_patchify_kernel(const float *__restrict__ img, int B, int C, int S, int P, float alpha, float beta,
+                                    float *__restrict__ out, long ld) {
+  const int n = S / P, pd = P * P * C;
+  const long total = (long)B * n * n * pd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % pd);
+    const long row = i / pd;
+    const int c = col % C, p2 = (col / C) % P, p1 = col / (C * P);
+    const int wx = (int)(row % n), hy = (int)((row / n) % n);
+    const long b = row / ((long)n * n);
+    out[row * ld + col] = alpha * img[((b * C + c) * S + hy * P + p1) * (long)S + wx * P + p2] + beta;
+  }
+}
+// exact (erf) GELU, nn.GELU's default
+__global__ void mmt_gelu_fwd_kernel(const float *__restrict__ z, float *__restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = 0.5f * z[i] * (1.0f + erff(z[i] * 0.70710678118654752f));
+}
+__global__ void mmt_gelu_bwd_kernel(const float *__restrict__ z, const float *__restrict__ dy, float *__restrict__ dz, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float v = z[i];
+    dz[i] = dy[i] * (0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.39894228040143268f * expf(-0.5f * v * v));
+  }
+}
+// dst[b][r][0..N) (+)= src[b][r][0..N): views with batch / row strides (a stride of 0 broadcasts the source)
+__global__ void mmt_copy3_kernel(const float *__restrict__ src, long sbs, long srs, float *__restrict__ dst, long dbs, long drs,
+                                 int B, int R, int N, int accumulate) {
+  const long total = (long)B * R * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % N);
+    const long br = i / N;
+    const int r = (int)(br % R);
+    const long b = br / R;
+    const float v = src[b * sbs + r * srs + c];
+    float *d = dst + b * dbs + r * drs + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
 __global__ void mmt_lr_step_kernel(float *state, float gamma) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     state[0] += 1.0f;
@@ -1245,6 +1287,34 @@ extern "C" int mmt_cumsum_axis(const float *x, long outer, int n, long inner, fl
   hipLaunchKernelGGL(mmt_cumsum_axis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, outer, n,
                      inner, y);
   return launch_ok("mmt_cumsum_axis");
+}
+
+extern "C" int mmt_patchify(const float *img, int B, int C, int S, int P, float alpha, float beta, float *out, long ld, void *stream) {
+  if (!img || !out || B <= 0 || C <= 0 || S <= 0 || P <= 0 || S % P || ld < (long)P * P * C)
+    return mmt_set_error(MMT_EINVAL, "mmt_patchify: bad arguments (image %d, patch %d, row stride %ld)", S, P, ld);
+  const long total = (long)B * S * S * C;
+  hipLaunchKernelGGL(mmt_patchify_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, img,
+                     B, C, S, P, alpha, beta, out, ld);
+  return launch_ok("mmt_patchify");
+}
+extern "C" int mmt_gelu_fwd(const float *z, float *y, long n, void *stream) {
+  if (!z || !y || n <= 0) return mmt_set_error(MMT_EINVAL, "mmt_gelu_fwd: bad arguments");
+  hipLaunchKernelGGL(mmt_gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, y, n);
+  return launch_ok("mmt_gelu_fwd");
+}
+extern "C" int mmt_gelu_bwd(const float *z, const float *dy, float *dz, long n, void *stream) {
+  if (!z || !dy || !dz || n <= 0) return mmt_set_error(MMT_EINVAL, "mmt_gelu_bwd: bad arguments");
+  hipLaunchKernelGGL(mmt_gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, dy, dz, n);
+  return launch_ok("mmt_gelu_bwd");
+}
+extern "C" int mmt_copy3(const float *src, long sbs, long srs, float *dst, long dbs, long drs, int B, int R, int N, int accumulate,
+                         void *stream) {
+  if (!src || !dst || B <= 0 || R <= 0 || N <= 0 || sbs < 0 || srs < 0 || dbs < 0 || drs < N)
+    return mmt_set_error(MMT_EINVAL, "mmt_copy3: bad arguments");
+  const long total = (long)B * R * N;
+  hipLaunchKernelGGL(mmt_copy3_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, src, sbs,
+                     srs, dst, dbs, drs, B, R, N, accumulate);
+  return launch_ok("mmt_copy3");
 }
 
 extern "C" int mmt_add_inplace(float *y, const float *x, long n, void *stream) {

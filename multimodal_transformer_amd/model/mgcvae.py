@@ -226,13 +226,13 @@ class MultimodalGenerativeCVAE(object):
                    prediction_horizon):
         """mgcvae.py:559-627 -> (loss, reg_loss), standardised units, dropout-free graph.
 
-        Basic, Map_encoding_CNN and Lane_encoding_CNN configurations: the returned scalar carries autograd -- ``loss.backward()`` runs the HIP
-        backward (training.py) and fills ``.grad`` of every parameter, so the reference's loop (train.py:244-253) works
-        unchanged; ``training.Trainer`` is the fused, graph-replayed equivalent of that whole loop body.
-        ViT configuration: forward value only (no backward kernels, parity unpinned)."""
+        All four configurations (Basic, Map_encoding_CNN, Map_encoding_ViT, Lane_encoding_CNN): the returned scalar carries
+        autograd -- ``loss.backward()`` runs the HIP backward (training.py) and fills ``.grad`` of every parameter, so the
+        reference's loop (train.py:244-253) works unchanged; ``training.Trainer`` is the fused, graph-replayed equivalent of
+        that whole loop body.  (ViT: checked against the CPU restatement's autograd only -- parity unpinned.)"""
         hp = self.hyperparams
         basic = not (hp["map_cnn_encoding"] or hp["map_vit_encoding"] or hp["lane_cnn_encoding"])
-        map_cnn = bool(hp["map_cnn_encoding"]) and hp["autoregressive"]
+        map_cnn = bool(hp["map_cnn_encoding"] or hp["map_vit_encoding"]) and hp["autoregressive"]
         if not hp["autoregressive"] and not basic:
             raise MmtError("teacher-forced training (non_at_dec) is only defined for the Basic configuration "
                            "(mgcvae.py:365-367 and :502 do not run in the reference)")
@@ -240,7 +240,7 @@ class MultimodalGenerativeCVAE(object):
             from ..training import train_loss_with_graph
             loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon,
                                          teacher_forced=not hp["autoregressive"])
-        elif map_cnn:       # the CNN map encoder and fusion/hist_map train too (their own parameter group in train.py:218-219)
+        elif map_cnn:       # the CNN / ViT map encoder and fusion/hist_map train too (their own parameter group in train.py:218-219)
             from ..training import train_loss_with_graph
             loss = train_loss_with_graph(self, inputs_st.contiguous(), labels_st.contiguous(), prediction_horizon,
                                          maps=map.contiguous())

@@ -180,18 +180,130 @@ class _CnnTape:
                 dz = P["dz"]
 
 
+class _VitTape:
+    """ViT map encoder for the training step (third-party vit_pytorch==0.33.2 architecture, call sites mgcvae.py:145-155,294-296;
+    parity unpinned): patch rearrange + Linear, cls / position tokens, pre-norm blocks
+    x += to_out(softmax(q k^T / sqrt(dh)) v), x += W2 gelu(W1 LN(x)), LayerNorm + Linear on the cls token.  Forward keeps what
+    the backward needs; every weight gradient is one GEMM over all B*(n+1) token rows.  Same interface as _CnnTape."""
+
+    def __init__(self, eng, vit, B, alpha=2.0, beta=-1.0):
+        cfg = vit._cfg()
+        self.vit, self.B, self.alpha, self.beta = vit, B, float(alpha), float(beta)
+        self.S, self.P, self.C = cfg["image_size"], cfg["patch_size"], cfg["channels"]
+        self.n = (self.S // self.P) ** 2
+        self.L = L = self.n + 1
+        self.d = d = cfg["dim"]
+        self.H, self.dh, self.f, self.n_out = cfg["heads"], cfg["dim_head"], cfg["mlp_dim"], cfg["num_classes"]
+        self.inner = inner = self.H * self.dh
+        self.scale = self.dh ** -0.5
+        if L > 32 or self.dh not in (16, 32, 64):
+            raise MmtError("ViT map encoder training: at most 31 patches and a head dimension of 16, 32 or 64")
+        self.in_shape = (B, self.C, self.S, self.S)
+        R = B * L
+        b = eng._buf
+        self.patches, self.pe, self.g_pe = b(B * self.n, self.P * self.P * self.C), b(B * self.n, d), b(B * self.n, d)
+        depth = len(vit.transformer.layers)
+        self.x = [b(B, L, d) for _ in range(2 * depth + 1)]      # block input, after attention, after feed-forward, ...
+        self.blocks = []
+        self.dqkv_all = b(depth, B, L, 3 * inner)                # dk / dv are accumulated into: one fill per step
+        for i, (attn, ff) in enumerate(vit.transformer.layers):
+            self.blocks.append(dict(
+                ln1=attn.norm, wqkv=attn.fn.to_qkv.weight, wo=attn.fn.to_out[0].weight, bo=attn.fn.to_out[0].bias,
+                ln2=ff.norm, w1=ff.fn.net[0].weight, b1=ff.fn.net[0].bias, w2=ff.fn.net[3].weight, b2=ff.fn.net[3].bias,
+                h1=b(R, d), xhat1=b(R, d), rstd1=b(R), qkv=b(B, L, 3 * inner), o=b(B, L, inner), probs=b(B, self.H, L, L),
+                h2=b(R, d), xhat2=b(R, d), rstd2=b(R), z=b(R, self.f), a=b(R, self.f), dqkv=self.dqkv_all[i]))
+        self.xc, self.hc, self.xhatc, self.rstdc, self.out = b(B, d), b(B, d), b(B, d), b(B), b(B, self.n_out)
+        self.gx, self.g_a, self.g_z, self.g_h, self.g_o = b(B, L, d), b(R, self.f), b(R, self.f), b(R, d), b(B, L, inner)
+        self.g_hc, self.g_xc = b(B, d), b(B, d)
+
+    def parameters(self):
+        return self.vit.parameters()
+
+    def _qkv(self, t):
+        i = self.inner
+        return t[:, :, 0:i], t[:, :, i:2 * i], t[:, :, 2 * i:3 * i]
+
+    def forward(self, raw):
+        """raw (B,C,S,S) in [0,1] -> encoded map (B, n_out); ``map*2-1`` (mgcvae.py:289-290) rides in the patch gather."""
+        v, B, L, d, n = self.vit, self.B, self.L, self.d, self.n
+        R = B * L
+        K.patchify(raw, self.P, self.patches, self.alpha, self.beta)
+        lin = v.to_patch_embedding[1]
+        K.gemm(self.patches, _t(lin.weight), self.pe, bias=lin.bias)
+        x0 = self.x[0]
+        K.copy3(v.pos_embedding[:, :L].expand(B, L, d), x0)
+        K.copy3(v.cls_token.expand(B, 1, d), x0[:, 0:1, :], accumulate=True)
+        K.copy3(self.pe.view(B, n, d), x0[:, 1:, :], accumulate=True)
+        for i, T in enumerate(self.blocks):
+            xin, xmid, xout = (self.x[2 * i + j].view(R, d) for j in range(3))
+            K.layernorm_fwd(xin, None, T["ln1"].weight, T["ln1"].bias, T["h1"], T["xhat1"], T["rstd1"])
+            K.gemm(T["h1"], _t(T["wqkv"]), T["qkv"].view(R, 3 * self.inner))
+            q, k, vv = self._qkv(T["qkv"])
+            K.attention_fwd(q, k, vv, T["o"], T["probs"], self.H, self.scale)
+            K.gemm(T["o"].view(R, self.inner), _t(T["wo"]), xmid, bias=T["bo"], addend=xin)
+            K.layernorm_fwd(xmid, None, T["ln2"].weight, T["ln2"].bias, T["h2"], T["xhat2"], T["rstd2"])
+            K.gemm(T["h2"], _t(T["w1"]), T["z"], bias=T["b1"])
+            K.gelu_fwd(T["z"], T["a"])
+            K.gemm(T["a"], _t(T["w2"]), xout, bias=T["b2"], addend=xmid)
+        K.copy3(self.x[-1][:, 0:1, :], self.xc.view(B, 1, d))                    # cls pooling
+        ln, fc = v.mlp_head[0], v.mlp_head[1]
+        K.layernorm_fwd(self.xc, None, ln.weight, ln.bias, self.hc, self.xhatc, self.rstdc)
+        K.gemm(self.hc, _t(fc.weight), self.out, bias=fc.bias)
+        return self.out
+
+    def backward(self, eng, g):
+        """g (B, n_out): gradient at the encoded map (any row stride)."""
+        v, B, L, d, n = self.vit, self.B, self.L, self.d, self.n
+        R = B * L
+        ln, fc = v.mlp_head[0], v.mlp_head[1]
+        eng._wgrad_rows(g, self.hc, eng.g(fc.weight), eng.g(fc.bias))
+        K.gemm(g, fc.weight, self.g_hc)
+        eng._ln_grad(self.g_hc, self.xhatc, ln)
+        K.layernorm_bwd(self.g_hc, self.xhatc, self.rstdc, ln.weight, self.g_xc)
+        self.gx.zero_()
+        self.dqkv_all.zero_()
+        K.copy3(self.g_xc.view(B, 1, d), self.gx[:, 0:1, :])
+        gx = self.gx.view(R, d)
+        for T in reversed(self.blocks):
+            # x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
+            eng._wgrad_rows(gx, T["a"], eng.g(T["w2"]), eng.g(T["b2"]))
+            K.gemm(gx, T["w2"], self.g_a)
+            K.gelu_bwd(T["z"], self.g_a, self.g_z)
+            eng._wgrad_rows(self.g_z, T["h2"], eng.g(T["w1"]), eng.g(T["b1"]))
+            K.gemm(self.g_z, T["w1"], self.g_h)
+            eng._ln_grad(self.g_h, T["xhat2"], T["ln2"])
+            K.layernorm_bwd(self.g_h, T["xhat2"], T["rstd2"], T["ln2"].weight, gx, accumulate=True)
+            # x_mid = x_in + Wo attention(LN1(x_in) Wqkv^T) + bo
+            eng._wgrad_rows(gx, T["o"].view(R, self.inner), eng.g(T["wo"]), eng.g(T["bo"]))
+            K.gemm(gx, T["wo"], self.g_o.view(R, self.inner))
+            q, k, vv = self._qkv(T["qkv"])
+            dq, dk, dv = self._qkv(T["dqkv"])
+            K.attention_bwd(q, k, vv, T["probs"], self.g_o, dq, dk, dv, self.H, self.scale)
+            dqkv = T["dqkv"].view(R, 3 * self.inner)
+            eng._wgrad_rows(dqkv, T["h1"], eng.g(T["wqkv"]), None)
+            K.gemm(dqkv, T["wqkv"], self.g_h)
+            eng._ln_grad(self.g_h, T["xhat1"], T["ln1"])
+            K.layernorm_bwd(self.g_h, T["xhat1"], T["rstd1"], T["ln1"].weight, gx, accumulate=True)
+        # tokens = cat[cls, patches W^T + b] + pos
+        gpos = eng.g(v.pos_embedding)
+        K.colsum(self.gx.view(B, L * d), gpos.view(L * d))
+        K.copy3(gpos.view(1, L, d)[:, 0:1, :], eng.g(v.cls_token).view(1, 1, d))
+        K.copy3(self.gx[:, 1:, :], self.g_pe.view(B, n, d))
+        lin = v.to_patch_embedding[1]
+        eng._wgrad_rows(self.g_pe, self.patches, eng.g(lin.weight), eng.g(lin.bias))
+
+
 class TrainEngine:
-    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic, Map_encoding_CNN or Lane_encoding_CNN configuration."""
+    """Forward-with-stash + backward for one (B, T, ph) shape of the Basic, Map_encoding_CNN, Map_encoding_ViT or
+    Lane_encoding_CNN configuration."""
 
     def __init__(self, model, B, T, ph, device=None, teacher_forced=None):
         hp = model.hyperparams
         # non_at_dec (mgcvae.py:310-373): tokens come from the labels, positions are the running sum of the head
         # outputs and are NOT fed back, so no gradient flows through the tokens
         self.teacher_forced = (not hp.get("autoregressive", True)) if teacher_forced is None else bool(teacher_forced)
-        if hp["map_vit_encoding"]:
-            raise MmtError("the HIP training step covers the Basic, Map_encoding_CNN and Lane_encoding_CNN configurations; the "
-                           "ViT map encoder has no backward kernels (and no pinned parity)")
-        self.map_mode = bool(hp["map_cnn_encoding"])
+        self.vit_mode = bool(hp["map_vit_encoding"])
+        self.map_mode = bool(hp["map_cnn_encoding"]) or self.vit_mode
         self.lane_mode = bool(hp["lane_cnn_encoding"])
         if (self.map_mode or self.lane_mode) and self.teacher_forced:
             raise MmtError("non_at_dec is only defined for the Basic configuration (mgcvae.py:365-367 does not run)")
@@ -329,7 +441,10 @@ class TrainEngine:
         self.head_tape = _MlpTape(self, self.head, ph, B)
         if self.map_mode:
             # head input = fusion/hist_map(cat[output_fc(x), encoded_map])   (mgcvae.py:438-443)
-            self.cnn_tape = _CnnTape(self, self.cnn.convs, self.cnn._strides(), self.cnn.fc, self.cnn.in_hw, B, 2.0, -1.0)
+            if self.vit_mode:
+                self.cnn_tape = _VitTape(self, self.cnn, B, 2.0, -1.0)
+            else:
+                self.cnn_tape = _CnnTape(self, self.cnn.convs, self.cnn._strides(), self.cnn.fc, self.cnn.in_hw, B, 2.0, -1.0)
             self.fuse_tape = _MlpTape(self, self.fuse, ph, B)
             md = self.cnn_tape.n_out
             if self.fuse_tape.k_in != no + md or self.fuse_tape.n_out != self.head_tape.k_in:
@@ -338,7 +453,7 @@ class TrainEngine:
             S.ho = S.hcat[:, :, :no]                       # output_fc writes straight into its columns of the concatenation
             S.u = b(ph, B, self.fuse_tape.n_out)
             S.gmap = b(B * (no + md))
-            self.maps = b(B, *self.cnn.convs[0].weight.shape[1:2], *self.cnn.in_hw)
+            self.maps = b(*self.cnn_tape.in_shape)
         else:
             if self.head_tape.k_in != no:
                 raise MmtError("decoder/MLP width does not match output_fc")

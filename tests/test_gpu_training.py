@@ -368,6 +368,54 @@ def test_map_cnn_step_matches_reference(tiny):
 
 
 @pytest.mark.parametrize("tiny", [True, False])
+def test_map_vit_step_matches_cpu_restatement_autograd(tiny):
+    """Map_encoding_ViT training step.  PARITY UNPINNED: vit_pytorch is not in the reference tree, so
+    the checker is the autograd of the CPU restatement of its published architecture (oracle/reference_form.py::MapViT), run
+    here on the same seeded weights and batch: loss, every gradient element-wise (tiny: ViT dim 32 / depth 2; full: the
+    shipped dim 256 / depth 6 / 8 heads at B = 8), dropout off."""
+    import copy
+    from multimodal_transformer_amd import training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    from oracle import reference_form as rf      # checker only
+    dev = _dev()
+    if tiny:
+        hp, B, ph = hp_for("map_vit", True)
+        hp = copy.deepcopy(hp)
+        hp["map_encoder"]["vit_param"].update(dim=32, deep=2, heads=2, mlp_dim=64)
+    else:
+        hp, B, ph = make_hyperparams("map_vit", history=8, horizon=12), 8, 12
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    batch = make_batch(B, hp["maximum_history_length"], ph, seed=5, with_map=True)
+    ref = rf.ReferenceFormModel(hp)
+    apply_recipe(ref.m, seed=0)
+    ref.m.train()
+    for m in ref.m.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    c = {k: torch.from_numpy(v) for k, v in batch.items()}
+    want_loss = ref.train_loss(c["x"], c["x_st"], c["y"], c["y_st"], None, c["map"], ph)
+    want_loss.backward()
+    want = {n: p.grad for n, p in ref.m.named_parameters() if p.grad is not None}
+    eng = training.TrainEngine(model, B, c["x_st"].shape[1], ph)
+    eng.set_batch(c["x_st"].to(dev), c["y_st"].to(dev), maps=c["map"].to(dev))
+    loss = eng.forward()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(want_loss)) <= TOL * abs(float(want_loss))
+    assert set(eng.grad_by_name) == set(want)
+    vit_names = [n for n in want if "map_encoder" in n]
+    assert len(vit_names) == 4 + 2 + (2 if tiny else 6) * 11 + 2
+    for name, g in eng.grad_by_name.items():
+        w = want[name].numpy()
+        assert rel_err(g.cpu().numpy(), w) <= (TOL if tiny else 5e-4), name
+
+
+@pytest.mark.parametrize("tiny", [True, False])
 def test_lane_cnn_step_matches_reference(tiny):
     """Lane_encoding_CNN training step: lane encoder (Conv1d as im2col + GEMM) and fusion/lane_hist train; tiny config
     element-wise, full config by norms / first 256 elements / post-AdamW parameters."""
