@@ -270,7 +270,7 @@ def main():
         n_dec_par = sum(p.numel() for k, m in reg.model_dict.items() if "decoder" in k or "fusion" in k
                         for p in m.parameters())
         dec_bytes = 4.0 * (n_dec_par + B * (args.history + 1) * hp["transformer"]["in_dim"] + B * ph * 2)
-        cluster = args.decoder != "persistent" and B <= 512 and args.history + 1 <= 16 and ph <= 16
+        cluster = args.decoder != "persistent" and B <= 1280 and args.history + 1 <= 16 and ph <= 16
         fused = cluster and args.decoder != "cluster_launches" and ((B + 3) // 4) * 8 <= 256 and not os.environ.get("MMT_NO_FUSED_DECODER")
         if fused:
             dec_kernel = ("mmt_dec_fused4_kernel (all %d phases of the decode in one launch, in-kernel cluster hand-offs) + "

@@ -520,14 +520,14 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
     if (kin != d + mem_feat_dim) return fail(MMT_EINVAL, "mmt_decoder_forward: memory fusion expects %d inputs, got d+mem_feat_dim=%d", kin, d + mem_feat_dim);
     if (dec->mem_fusion.out.n != d) return fail(MMT_EINVAL, "mmt_decoder_forward: memory fusion must output d_model");
   }
-  // AUTO: the cluster kernels win while one cluster round fits the chip (16 agents x nhead workgroups each, <= #CUs
-  // workgroups: B <= 512 at 8 heads on MI355X); beyond that the persistent kernel's larger tiles are faster.
+  // AUTO: the cluster kernels win up to ~2.5 rounds of 16-agent clusters x nhead workgroups over the chip (measured on MI355X,
+  // 8 heads: B = 1024: 4.7 vs 5.1 ms, B = 2048: 9.1 vs 6.1 ms); beyond that the persistent kernel's weight reuse is faster.
   bool use_cluster = cluster_ok && g_decoder_impl != MMT_DECODER_PERSISTENT;
   if (use_cluster && g_decoder_impl != MMT_DECODER_CLUSTER) {
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    use_cluster = ((B + 15) / 16) * dec->nhead <= ncu;
+    use_cluster = 2 * ((B + 15) / 16) * dec->nhead <= 5 * ncu;
   }
   if (use_cluster)
     return mmt_cluster_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T,
