@@ -373,6 +373,14 @@ int mmt_batch_gather(const double *table, const int64_t *row_off, const int32_t 
                      const int32_t *node_idx, const int32_t *ts, int B, int max_ht, int max_ft, int ncol,
                      const int32_t *pred_col, int npred, double scale, int64_t *first_history_index, float *x, float *y,
                      float *x_st, float *y_st, void *stream);
+/* Lane part of a batch element (preprocessing.py:170-202, collate :43-45, trajectron.py:62-65): lanes = the nodes' lane tables
+ * (fp64, metres), one (n_lanes, n_points, 2) block per row of `table` (Node.lanes_point[t - first_timestep]);
+ * lane_input (B,n_lanes,n_points,2) = points / 80; lane_t_mask (B,n_lanes) uint8 = the lane's first two points differ;
+ * lane_label (B,max_ft,n_lanes) = one-hot of the lane nearest to each standardised future position (np.argmin semantics). */
+int mmt_lane_gather(const double *table, const double *lanes, const int64_t *row_off, const int32_t *first,
+                    const int32_t *last, const int32_t *node_idx, const int32_t *ts, int B, int max_ft, int ncol,
+                    int n_lanes, int n_points, double scale, float *lane_input, float *lane_label, uint8_t *lane_mask,
+                    void *stream);
 
 #ifdef __cplusplus
 }

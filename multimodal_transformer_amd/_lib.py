@@ -113,6 +113,8 @@ SIGNATURES = {
     "mmt_pack_linear": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_batch_gather": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                    C.c_int, C.c_double, fptr, fptr, fptr, fptr, fptr, C.c_void_p]),
+    "mmt_lane_gather": (C.c_int, [fptr, fptr, fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                  fptr, fptr, fptr, C.c_void_p]),
     "mmt_pack_jobs": (C.c_int, [fptr, C.c_int, C.c_void_p]),
     "mmt_lin4_first_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mmt_pack_lin4_first": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),

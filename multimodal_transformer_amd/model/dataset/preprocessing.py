@@ -32,7 +32,7 @@ class SceneTable:
     """The state columns of every node of one type in a scene, packed node after node (fp64, as the reference holds them),
     plus first / last timestep per node -- resident on the device."""
 
-    def __init__(self, tables, firsts, nodes, device):
+    def __init__(self, tables, firsts, nodes, device, lane_tables=None):
         self.nodes = list(nodes)
         lengths = np.array([len(t) for t in tables], dtype=np.int64)
         if len(tables) == 0:
@@ -48,13 +48,24 @@ class SceneTable:
         self.row_off = torch.from_numpy(self.row_off_h).to(self.device)
         self.first = torch.from_numpy(self.first_h).to(self.device)
         self.last = torch.from_numpy(self.last_h).to(self.device)
+        # lane tables (Node.lanes_point, node.py:119-121): one (n_lanes, n_points, 2) block per state row, metres
+        self.lanes = None
+        if lane_tables is not None:
+            lt = [np.asarray(t, dtype=np.float64) for t in lane_tables]
+            if any(t.ndim != 4 or t.shape[1:] != lt[0].shape[1:] or t.shape[3] != 2 or len(t) < n for t, n in zip(lt, lengths)):
+                raise MmtError("SceneTable: every node needs a lane table of shape (timesteps, n_lanes, n_points, 2)")
+            self.n_lanes, self.n_points = int(lt[0].shape[1]), int(lt[0].shape[2])
+            flat_l = np.ascontiguousarray(np.concatenate([t[:n] for t, n in zip(lt, lengths)], axis=0))
+            self.lanes = torch.from_numpy(flat_l).to(self.device)
 
     @classmethod
     def from_scene(cls, scene, node_type, state_of_type, device="cuda", return_robot=True):
         """One host pass over the nodes (``node.data[:, state]``: environment/data_structures.py DoubleHeaderNumpyArray)."""
         nodes = [n for n in scene.nodes if n.type == node_type and (return_robot or not getattr(n, "is_robot", False))]
         tables = [np.asarray(n.data[:, state_of_type], dtype=np.float64) for n in nodes]
-        return cls(tables, [int(n.first_timestep) for n in nodes], nodes, device)
+        lanes = [getattr(n, "lanes_point", None) for n in nodes]
+        return cls(tables, [int(n.first_timestep) for n in nodes], nodes, device,
+                   lane_tables=lanes if nodes and all(l is not None for l in lanes) else None)
 
 
 def present_nodes(first, last, timesteps, min_history_timesteps=0, min_future_timesteps=0):
@@ -94,6 +105,26 @@ def gather(table: SceneTable, node_idx, ts, max_ht, max_ft, pred_cols=(0, 1)):
     return fhi, x, y, x_st, y_st
 
 
+def gather_lanes(table: SceneTable, node_idx, ts, max_ft):
+    """[lane_input (B,Ln,P,2) f32, lane_label (B,max_ft,Ln) f32, lane_t_mask (B,Ln) bool] on the device: the lane tuple of
+    preprocessing.py:170-202 after collate (:43-45) and the stacking of trajectron.py:62-65."""
+    if table.lanes is None:
+        raise MmtError("lane batches need Node.lanes_point on every node of the scene (Node.get_lane_id, node.py:119-121)")
+    B, dev = len(node_idx), table.device
+    ni = torch.from_numpy(np.ascontiguousarray(node_idx, dtype=np.int32)).to(dev)
+    tt = torch.from_numpy(np.ascontiguousarray(ts, dtype=np.int32)).to(dev)
+    Ln, P = table.n_lanes, table.n_points
+    lane_input = torch.empty(B, Ln, P, 2, dtype=torch.float32, device=dev)
+    lane_label = torch.empty(B, max_ft, Ln, dtype=torch.float32, device=dev)
+    lane_mask = torch.empty(B, Ln, dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.mmt_lane_gather(p(table.table), p(table.lanes), p(table.row_off), p(table.first), p(table.last), p(ni), p(tt), B,
+                                   int(max_ft), table.ncol, Ln, P, STANDARDIZE_DIVISOR, p(lane_input), p(lane_label), p(lane_mask),
+                                   _stream()), "mmt_lane_gather")
+    return [lane_input, lane_label, lane_mask.bool()]
+
+
 def _table_for(scene, node_type, state_of_type, device, return_robot):
     cache = scene.__dict__.setdefault("_mmt_scene_tables", {})
     key = (str(node_type), tuple(_state_columns(state_of_type)), str(device), bool(return_robot))
@@ -126,8 +157,7 @@ def get_timesteps_data(env, scene, t, node_type, state, pred_state, edge_types, 
         cur = table.flat_h[table.row_off_h[node_idx] + (out_ts - table.first_h[node_idx])]     # x[-1] in fp64 (:150,166)
         maps = _map_patches(scene, node_type, len(nodes), cur, hyperparams, str(x.device))
     elif hyperparams.get("lane_cnn_encoding"):
-        raise MmtError("lane batches need the per-node lane tables of the nuScenes preprocessing (outside the hot path): "
-                       "pass lanes to Trajectron.predict_batch directly")
+        lanes = gather_lanes(table, node_idx, out_ts, max_ft)
     return (fhi, x, y, x_st, y_st, None, None, None, lanes, maps), nodes, [int(v) for v in out_ts]
 
 
@@ -140,7 +170,10 @@ def get_node_timestep_data(env, scene, t, node, state, pred_state, edge_types, m
     cols = _state_columns(st)
     pred_cols = [cols.index(c) for c in _state_columns(pred_state[node.type])]
     fhi, x, y, x_st, y_st = gather(table, np.array([idx]), np.array([int(t)]), max_ht, max_ft, pred_cols)
-    return fhi[0], x[0], y[0], x_st[0], y_st[0], None, None, None, None, None
+    lane_tuple = None
+    if hyperparams.get("lane_cnn_encoding"):
+        lane_tuple = tuple(v[0] for v in gather_lanes(table, np.array([idx]), np.array([int(t)]), max_ft))
+    return fhi[0], x[0], y[0], x_st[0], y_st[0], None, None, None, lane_tuple, None
 
 
 def _map_patches(scene, node_type, n, cur, hyperparams, device):

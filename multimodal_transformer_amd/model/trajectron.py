@@ -48,7 +48,9 @@ class Trajectron(object):
         (_, x_t, y_t, x_st_t, y_st_t, _, _, _robot, lanes, map) = batch
         lane_input = None
         if self.hyperparams["lane_cnn_encoding"]:
-            lane_input = torch.as_tensor(np.array(lanes[0]), dtype=torch.float32).to(self.device)
+            # reference batches: a tuple of (Ln,P,2) arrays (trajectron.py:62-63); the vectorised builder: one device tensor
+            lane_input = lanes[0] if torch.is_tensor(lanes[0]) else torch.as_tensor(np.array(lanes[0]), dtype=torch.float32)
+            lane_input = lane_input.to(self.device)
         dev = lambda t: t.to(self.device) if isinstance(t, torch.Tensor) else None
         return dev(x_t), dev(y_t), dev(x_st_t), dev(y_st_t), lane_input, dev(map)
 

@@ -7,7 +7,9 @@ CPU restatement, in plain numpy loops, of the reference's batch construction (SU
                               padding outside the node's lifetime) and environment/environment.py:49-61 (``standardize``
                               subtracts the mean and divides by 80, whatever std is passed);
   * ``timesteps_data``     -- preprocessing.py:208-270 (+ ``collate``: stack).
-Pinned against the reference's own outputs in tests/golden/batch.npz (tests/test_oracle_golden.py).
+  * ``lane_tuple``         -- preprocessing.py:170-202 (lane points / 80, lane mask, one-hot label of the nearest lane for
+                              every future position) with collate :43-45 and trajectron.py:62-65 (stacking).
+Pinned against the reference's own outputs in tests/golden/batch.npz / batch_lane.npz (tests/test_oracle_golden.py).
 """
 import numpy as np
 
@@ -63,3 +65,23 @@ def timesteps_data(table, row_off, first, last, timesteps, min_ht, max_ht, max_f
         return None
     fhi = np.array([e[0] for e in elems], dtype=np.int64)
     return (fhi,) + tuple(np.stack([e[k] for e in elems]) for k in range(1, 5)), np.array(nodes), np.array(out_ts)
+
+
+def lane_tuple(rows, lane_rows, first, t, max_ft):
+    """(lane_input (Ln,P,2) f32, lane_label (max_ft,Ln) f32, lane_t_mask (Ln) bool) of one batch element.
+    rows = the node's state table (fp64, position first), lane_rows = its lane table (timesteps, Ln, P, 2) in metres."""
+    last = first + len(rows) - 1
+    y = node_get(rows, first, last, t + 1, t + max_ft, [0, 1])
+    y_st = np.where(np.isnan(y), np.nan, (y - rows[t - first][0:2]) / SCALE)           # fp64, :114-116
+    pts = np.array(lane_rows[t - first]) / 80                                          # :190-192 (history_points_at = t - first)
+    mask = np.linalg.norm(pts[:, 0] - pts[:, 1], axis=1) != 0                          # :193-194 (dtype=torch.bool)
+    label = np.zeros((max_ft, pts.shape[0]), dtype=np.float32)
+    for j, point in enumerate(y_st):                                                   # :196-200
+        dist = []
+        for i, lp in enumerate(pts):                                                   # get_gt_lane, :173-188
+            if not mask[i]:
+                dist.append(1e10)
+                continue
+            dist.append(np.abs(np.cross(lp[1] - lp[0], point - lp[0])) / np.abs(np.linalg.norm(lp[1] - lp[0])))
+        label[j, int(np.argmin(dist))] = 1.0
+    return pts.astype(np.float32), label, mask

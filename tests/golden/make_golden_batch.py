@@ -87,6 +87,45 @@ def main():
     np.savez_compressed(os.path.join(HERE, "batch.npz"), **out)
     json.dump(meta, open(os.path.join(HERE, "batch.json"), "w"), indent=1)
     print(meta)
+    lane_golden(env, scene, tables, firsts, rng)
+
+
+def lane_golden(env, scene, tables, firsts, rng):
+    """Lane batches (preprocessing.py:170-202 + collate :43-45): every node gets a lane table (timesteps x 3 lanes x 10 points
+    x 2, metres, as Node.get_lane_id stores it); absent lanes are the constant -100 m point (lane_utils.py:279-282)."""
+    lanes = []
+    for node, data in zip(scene.nodes, tables):
+        n = len(data)
+        lp = np.empty((n, 3, 10, 2))
+        for i in range(n):
+            for l in range(3):
+                if rng.random() < 0.25:
+                    lp[i, l] = -100.0                                    # absent lane
+                else:
+                    d = rng.normal(size=2)
+                    start = data[i, :2] + rng.normal(size=2) * 6.0
+                    lp[i, l] = start + np.outer(np.linspace(0.1, 1.0, 10), d / np.linalg.norm(d)) * rng.uniform(3, 30)
+        node.get_lane_id(lp, [["a", "b", "c"]] * n)
+        lanes.append(lp)
+    out = {"lanes": np.concatenate(lanes, axis=0)}
+    hp = dict(HP, lane_cnn_encoding=True)
+    meta = {}
+    for tag, (ts, min_ht, max_ht, max_ft) in {"lane_range": (np.arange(6, 40), 1, 8, 12), "lane_short": (np.arange(0, 47), 0, 4, 3)}.items():
+        batch, nodes, out_ts = get_timesteps_data(env=env, scene=scene, t=ts, node_type=env.NodeType.VEHICLE, state=STATE,
+                                                  pred_state=PRED, edge_types=env.get_edge_types(), min_ht=min_ht, max_ht=max_ht,
+                                                  min_ft=max_ft, max_ft=max_ft, hyperparams=hp)
+        lane_pts, y_lane, lane_mask = batch[8]
+        out[f"{tag}::t"] = ts
+        out[f"{tag}::lane_input"] = torch.tensor(np.array(lane_pts), dtype=torch.float32).numpy()     # trajectron.py:62-63
+        out[f"{tag}::lane_label"] = torch.stack(y_lane).numpy()                                        # trajectron.py:64
+        out[f"{tag}::lane_t_mask"] = torch.stack(lane_mask).numpy()                                    # trajectron.py:65
+        out[f"{tag}::x_st"] = batch[3].numpy()
+        out[f"{tag}::nodes"] = np.array([int(nd.id) for nd in nodes], dtype=np.int32)
+        out[f"{tag}::timesteps"] = np.array(out_ts, dtype=np.int32)
+        meta[tag] = dict(min_ht=min_ht, max_ht=max_ht, max_ft=max_ft, B=len(nodes))
+    np.savez_compressed(os.path.join(HERE, "batch_lane.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "batch_lane.json"), "w"), indent=1)
+    print(meta)
 
 
 if __name__ == "__main__":

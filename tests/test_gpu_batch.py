@@ -29,12 +29,13 @@ class _Data:
 
 
 class _Node:          # hashable like the reference's Node (node.py:47-60)
-    def __init__(self, i, first, table):
+    def __init__(self, i, first, table, lanes=None):
         self.type, self.id, self.first_timestep, self.is_robot, self.data = "VEHICLE", str(i), int(first), False, _Data(table)
+        self.lanes_point = lanes
 
 
-def _scene(tables, firsts):
-    nodes = [_Node(i, f, t) for i, (t, f) in enumerate(zip(tables, firsts))]
+def _scene(tables, firsts, lanes=None):
+    nodes = [_Node(i, f, t, None if lanes is None else lanes[i]) for i, (t, f) in enumerate(zip(tables, firsts))]
     return types.SimpleNamespace(nodes=nodes, map=None)
 
 
@@ -111,3 +112,47 @@ def test_predict_from_a_scene_through_trajectron():
     assert sorted(hist.keys()) == [10, 11, 12, 13]
     n_total = sum(len(v) for v in hist.values())
     assert n_total > 0 and all(a.shape == (1, 1, 12, 2) and np.isfinite(a).all() for v in hist.values() for a in v.values())
+
+
+def test_lane_batches_equal_reference_outputs():
+    """Lane_encoding_CNN batches (lane points / 80, lane mask, nearest-lane labels of preprocessing.py:170-202) from
+    mmt_lane_gather == what the reference's get_timesteps_data returned for the same scene (tests/golden/batch_lane.npz):
+    bit-exact; and the batch drives Trajectron.predict end to end."""
+    from multimodal_transformer_amd.model.dataset import get_timesteps_data, get_node_timestep_data
+    z = np.load(os.path.join(GOLD, "batch.npz"))
+    zl = np.load(os.path.join(GOLD, "batch_lane.npz"))
+    meta = json.load(open(os.path.join(GOLD, "batch_lane.json")))
+    scene = _scene(_split(z["table"], z["lengths"]), z["first"], _split(zl["lanes"], z["lengths"]))
+    hp = dict(HP, lane_cnn_encoding=True)
+    for tag, m in meta.items():
+        batch, nodes, out_ts = get_timesteps_data(env=None, scene=scene, t=zl[f"{tag}::t"], node_type="VEHICLE", state=STATE,
+                                                  pred_state=PRED, edge_types=None, min_ht=m["min_ht"], max_ht=m["max_ht"],
+                                                  min_ft=m["max_ft"], max_ft=m["max_ft"], hyperparams=hp)
+        assert [int(n.id) for n in nodes] == zl[f"{tag}::nodes"].tolist() and out_ts == zl[f"{tag}::timesteps"].tolist()
+        lane_input, lane_label, lane_mask = batch[8]
+        assert lane_input.is_cuda and lane_mask.dtype == torch.bool
+        assert np.array_equal(batch[3].cpu().numpy(), zl[f"{tag}::x_st"], equal_nan=True)
+        assert np.array_equal(lane_input.cpu().numpy(), zl[f"{tag}::lane_input"])
+        assert np.array_equal(lane_label.cpu().numpy(), zl[f"{tag}::lane_label"])
+        assert np.array_equal(lane_mask.cpu().numpy(), zl[f"{tag}::lane_t_mask"])
+    i = int(zl["lane_range::nodes"][5])
+    one = get_node_timestep_data(None, scene, int(zl["lane_range::timesteps"][5]), scene.nodes[i], STATE, PRED, None, 8, 12, hp)
+    assert np.array_equal(one[8][1].cpu().numpy(), zl["lane_range::lane_label"][5])
+    # end to end: lane batches from the scene through Trajectron.predict (three lane trajectories per node)
+    from helpers import TINY_TR
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.model import ModelRegistrar
+    from multimodal_transformer_amd.model.trajectron import Trajectron
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = torch.device("cuda:0")
+    hpm = make_hyperparams("lane_cnn", history=8, horizon=12, transformer=TINY_TR)
+    hpm.update(hp)
+    env = types.SimpleNamespace(NodeType=["VEHICLE"], get_edge_types=lambda: [], robot_type=None)
+    reg = ModelRegistrar("/tmp", dev)
+    tr = Trajectron(reg, hpm, None, dev, get_timesteps_data=get_timesteps_data)
+    tr.set_environment(env)
+    apply_recipe(reg.model_dict, seed=3)
+    hist, lane = tr.predict(scene, np.arange(10, 13), 12, min_future_timesteps=12, min_history_timesteps=1)
+    assert sorted(lane.keys()) == [10, 11, 12]
+    assert all(len(per_node) == 3 and all(np.isfinite(a).all() for a in per_node.values())
+               for v in lane.values() for per_node in v.values())

@@ -121,3 +121,26 @@ def test_batch_construction_oracle_matches_reference_outputs():
     assert ob.timesteps_data(table, row_off, first, last, np.array([47]), 1, 8, 12) is None
     ni, _ = present_nodes(first, last, np.array([47]), 1, 12)
     assert ni.size == 0
+
+
+def test_lane_batch_oracle_matches_reference_outputs():
+    """oracle/batch.py::lane_tuple == the lane tuples the reference's get_timesteps_data returned for the same synthetic scene
+    (tests/golden/batch_lane.npz, made by make_golden_batch.py with lane_cnn_encoding on): bit-exact."""
+    import json
+    import os
+    from oracle import batch as ob
+    GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(GOLD, "batch.npz"))
+    zl = np.load(os.path.join(GOLD, "batch_lane.npz"))
+    meta = json.load(open(os.path.join(GOLD, "batch_lane.json")))
+    first, lengths = z["first"], z["lengths"]
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    for tag, m in meta.items():
+        nodes, ts = zl[f"{tag}::nodes"], zl[f"{tag}::timesteps"]
+        for i in range(0, len(nodes), 7):
+            n, t = int(nodes[i]), int(ts[i])
+            rows, lanes = z["table"][off[n]:off[n + 1]], zl["lanes"][off[n]:off[n + 1]]
+            pts, label, mask = ob.lane_tuple(rows, lanes, int(first[n]), t, m["max_ft"])
+            assert np.array_equal(pts, zl[f"{tag}::lane_input"][i])
+            assert np.array_equal(label, zl[f"{tag}::lane_label"][i])
+            assert np.array_equal(mask, zl[f"{tag}::lane_t_mask"][i])
