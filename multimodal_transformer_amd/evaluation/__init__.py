@@ -1,1 +1,2 @@
-from .evaluation import compute_ade, compute_fde, batch_ade_fde  # noqa: F401
+from .evaluation import (compute_ade, compute_fde, batch_ade_fde, compute_batch_statistics,  # noqa: F401
+                         lane_compute_batch_statistics)

@@ -102,3 +102,34 @@ class Trajectron(object):
                 for i, ts in enumerate(timesteps_o):
                     hist_dict.setdefault(ts, dict())[nodes[i]] = arr[i][None, None]
         return hist_dict, lane_dict
+
+    def evaluate(self, scene, timesteps, ph, min_history_timesteps=1):
+        """The body of evaluate.py's scene loop (evaluate.py:99-148: predict with min_future_timesteps=ph, then
+        compute_batch_statistics / lane_compute_batch_statistics) without leaving the device: batch construction, predict and
+        the ADE / FDE reduction (best-of-lanes in lane mode) against the batch's own futures.  Returns
+        ``{node_type: {'ade': (B,) array, 'fde': (B,) array, 'nodes': [...], 'timesteps': [...]}}`` in the reference's visiting order."""
+        from ..evaluation import batch_ade_fde
+        if self.get_timesteps_data is None:
+            raise NotImplementedError("construct Trajectron with get_timesteps_data=<batch builder>")
+        out = dict()
+        for node_type in self.env.NodeType:
+            if node_type not in self.pred_state or node_type not in self.node_models_dict:
+                continue
+            model = self.node_models_dict[node_type]
+            batch = self.get_timesteps_data(
+                env=self.env, scene=scene, t=timesteps, node_type=node_type, state=self.state, pred_state=self.pred_state,
+                edge_types=model.edge_types, min_ht=min_history_timesteps, max_ht=self.max_ht, min_ft=ph, max_ft=ph,
+                hyperparams=self.hyperparams)
+            if batch is None:
+                continue
+            tensors, nodes, timesteps_o = batch
+            hist, lane = self.predict_batch(tensors, node_type, ph)
+            y = tensors[2].to(self.device)
+            pred = lane if self.hyperparams["lane_cnn_encoding"] else hist
+            # relative to the current position (column 0:2 of the last history row): keeps the fp32 reduction exact to ~1e-6 m
+            now = tensors[1].to(self.device)[:, -1, 0:2]
+            rel = pred - (now[:, None, None, :] if pred.dim() == 4 else now[:, None, :])
+            ade, fde = batch_ade_fde(rel.contiguous(), (y - now[:, None, :]).contiguous())
+            out[node_type] = {"ade": ade.cpu().numpy(), "fde": fde.cpu().numpy(), "nodes": nodes, "timesteps": timesteps_o}
+        return out
+

@@ -9,7 +9,10 @@ CPU restatement, in plain numpy loops, of the reference's batch construction (SU
   * ``timesteps_data``     -- preprocessing.py:208-270 (+ ``collate``: stack).
   * ``lane_tuple``         -- preprocessing.py:170-202 (lane points / 80, lane mask, one-hot label of the nearest lane for
                               every future position) with collate :43-45 and trajectron.py:62-65 (stacking).
-Pinned against the reference's own outputs in tests/golden/batch.npz / batch_lane.npz (tests/test_oracle_golden.py).
+  * ``ade_fde`` / ``batch_statistics`` -- evaluation/evaluation.py:10-19 (compute_ade / compute_fde) and :64-163 (the per-node
+                              loops of compute_batch_statistics / lane_compute_batch_statistics, best-of-lanes).
+Pinned against the reference's own outputs in tests/golden/batch.npz / batch_lane.npz / evalstats.npz
+(tests/test_oracle_golden.py).
 """
 import numpy as np
 
@@ -85,3 +88,19 @@ def lane_tuple(rows, lane_rows, first, t, max_ft):
             dist.append(np.abs(np.cross(lp[1] - lp[0], point - lp[0])) / np.abs(np.linalg.norm(lp[1] - lp[0])))
         label[j, int(np.argmin(dist))] = 1.0
     return pts.astype(np.float32), label, mask
+
+
+def ade_fde(pred, future):
+    """compute_ade / compute_fde (evaluation.py:10-19) of one (ph,2) prediction against the (ph,2) future."""
+    err = np.linalg.norm(pred.astype(np.float64) - future, axis=-1)
+    return float(np.mean(err)), float(np.linalg.norm(pred[-1].astype(np.float64) - future[-1]))
+
+
+def batch_statistics(preds, futures):
+    """preds: per node (ph,2) or (L,ph,2) (lanes: the minimum over L, evaluation.py:153-156); -> (ade, fde) arrays."""
+    ade, fde = [], []
+    for p, f in zip(preds, futures):
+        per = [ade_fde(q, f) for q in (p if p.ndim == 3 else p[None])]
+        ade.append(min(a for a, _ in per))
+        fde.append(min(b for _, b in per))
+    return np.array(ade), np.array(fde)

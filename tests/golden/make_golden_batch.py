@@ -88,6 +88,51 @@ def main():
     json.dump(meta, open(os.path.join(HERE, "batch.json"), "w"), indent=1)
     print(meta)
     lane_golden(env, scene, tables, firsts, rng)
+    stats_golden(env, scene, rng)
+
+
+def _reference_evaluation():
+    """Transformer/evaluation/evaluation.py, loaded from its file.  Its module-level imports pull in seaborn (visualization) and
+    the nuScenes devkit (utils.lane_utils), which the image lacks and which compute_batch_statistics never touches: ``utils`` is
+    served by the reference's own utils/trajectory_utils.py (also loaded from its file), ``visualization`` by an empty stub."""
+    import importlib.util
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    sys.modules["utils"] = load("utils", os.path.join(REF, "utils", "trajectory_utils.py"))          # reference
+    sys.modules["visualization"] = types.ModuleType("visualization")
+    return load("ref_evaluation", os.path.join(REF, "evaluation", "evaluation.py"))                  # reference
+
+
+def stats_golden(env, scene, rng):
+    """compute_batch_statistics / lane_compute_batch_statistics (evaluation.py:64-163) on synthetic prediction dicts
+    ({t: {node: (1,1,ph,2)}} and {t: {node: {lane: (1,1,ph,2)}}}, trajectron.py:216-221) over the same scene."""
+    ev = _reference_evaluation()
+    ph, max_hl = 12, 8
+    vt = env.NodeType.VEHICLE
+    pos = {"position": ["x", "y"]}
+    pred, lane_pred = {}, {}
+    node_ids, tss, arrs, lane_arrs = [], [], [], []
+    for t in (8, 15, 20, 31):
+        for node in scene.present_nodes(np.array([t]), type=vt, min_history_timesteps=1, min_future_timesteps=ph).get(t, []):
+            fut = node.get(np.array([t + 1, t + ph]), pos)
+            a = (fut + rng.normal(size=fut.shape) * 2.0).astype(np.float32)[None, None]
+            pred.setdefault(t, {})[node] = a
+            la = [(fut + rng.normal(size=fut.shape) * 3.0).astype(np.float32)[None, None] for _ in range(3)]
+            lane_pred.setdefault(t, {})[node] = {k: la[k] for k in range(3)}
+            node_ids.append(int(node.id)), tss.append(t), arrs.append(a[0, 0]), lane_arrs.append(np.stack([x[0, 0] for x in la]))
+    one = ev.compute_batch_statistics(pred, scene.dt, max_hl=max_hl, ph=ph, node_type_enum=env.NodeType, map=None,
+                                      prune_ph_to_future=False)
+    lane = ev.lane_compute_batch_statistics(lane_pred, scene.dt, max_hl=max_hl, ph=ph, node_type_enum=env.NodeType, map=None,
+                                            prune_ph_to_future=False)
+    out = {"nodes": np.array(node_ids, dtype=np.int32), "timesteps": np.array(tss, dtype=np.int32), "pred": np.stack(arrs),
+           "lane_pred": np.stack(lane_arrs), "ade": np.array(one[vt]["ade"]), "fde": np.array(one[vt]["fde"]),
+           "lane_ade": np.array(lane[vt]["ade"]), "lane_fde": np.array(lane[vt]["fde"]),
+           "kde": np.array(one[vt]["kde"], dtype=np.float64), "obs_viols": np.array(one[vt]["obs_viols"], dtype=np.float64)}
+    np.savez_compressed(os.path.join(HERE, "evalstats.npz"), **out)
+    print("evalstats", len(node_ids), float(out["ade"].mean()), float(out["lane_ade"].mean()))
 
 
 def lane_golden(env, scene, tables, firsts, rng):

@@ -33,6 +33,16 @@ class _Node:          # hashable like the reference's Node (node.py:47-60)
         self.type, self.id, self.first_timestep, self.is_robot, self.data = "VEHICLE", str(i), int(first), False, _Data(table)
         self.lanes_point = lanes
 
+    def get(self, tr_scene, state):       # Node.get for the position state (node.py:101-117): inclusive range, NaN padding
+        assert state == {"position": ["x", "y"]}
+        t0, t1 = int(tr_scene[0]), int(tr_scene[1])
+        out = np.full((t1 - t0 + 1, 2), np.nan)
+        last = self.first_timestep + len(self.data.arr) - 1
+        for j, t in enumerate(range(t0, t1 + 1)):
+            if self.first_timestep <= t <= last:
+                out[j] = self.data.arr[t - self.first_timestep, 0:2]
+        return out
+
 
 def _scene(tables, firsts, lanes=None):
     nodes = [_Node(i, f, t, None if lanes is None else lanes[i]) for i, (t, f) in enumerate(zip(tables, firsts))]
@@ -156,3 +166,48 @@ def test_lane_batches_equal_reference_outputs():
     assert sorted(lane.keys()) == [10, 11, 12]
     assert all(len(per_node) == 3 and all(np.isfinite(a).all() for a in per_node.values())
                for v in lane.values() for per_node in v.values())
+
+
+def test_batch_statistics_equal_reference_outputs():
+    """compute_batch_statistics / lane_compute_batch_statistics with the reference's signatures, reduced on the GPU == what the
+    reference's own functions returned for the same prediction dicts (tests/golden/evalstats.npz): ADE / FDE within 1e-3 m
+    (north star), same order; and Trajectron.evaluate (device-resident) == the dict route."""
+    from multimodal_transformer_amd.evaluation import compute_batch_statistics, lane_compute_batch_statistics
+    z = np.load(os.path.join(GOLD, "batch.npz"))
+    ze = np.load(os.path.join(GOLD, "evalstats.npz"))
+    scene = _scene(_split(z["table"], z["lengths"]), z["first"])
+    pred, lane_pred = {}, {}
+    for i, (n, t) in enumerate(zip(ze["nodes"], ze["timesteps"])):
+        node = scene.nodes[int(n)]
+        pred.setdefault(int(t), {})[node] = ze["pred"][i][None, None]
+        lane_pred.setdefault(int(t), {})[node] = {k: ze["lane_pred"][i, k][None, None] for k in range(3)}
+    one = compute_batch_statistics(pred, 0.5, max_hl=8, ph=12, node_type_enum=["VEHICLE"], map=None, prune_ph_to_future=False)
+    lane = lane_compute_batch_statistics(lane_pred, 0.5, max_hl=8, ph=12, node_type_enum=["VEHICLE"], map=None,
+                                         prune_ph_to_future=False)
+    assert len(one["VEHICLE"]["ade"]) == len(ze["ade"]) and one["VEHICLE"]["kde"] == [0] * len(ze["ade"])
+    for got, want in ((one["VEHICLE"]["ade"], ze["ade"]), (one["VEHICLE"]["fde"], ze["fde"]),
+                      (lane["VEHICLE"]["ade"], ze["lane_ade"]), (lane["VEHICLE"]["fde"], ze["lane_fde"])):
+        assert np.max(np.abs(np.array(got) - want)) <= 1e-4        # (bar: 1e-3 m)
+    with pytest.raises(NotImplementedError):
+        compute_batch_statistics(pred, 0.5, max_hl=8, ph=12, node_type_enum=["VEHICLE"], kde=True)
+    # device-resident route == predict + dicts + statistics
+    from helpers import TINY_TR
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.model import ModelRegistrar
+    from multimodal_transformer_amd.model.trajectron import Trajectron
+    from multimodal_transformer_amd.model.dataset import get_timesteps_data
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = torch.device("cuda:0")
+    hp = make_hyperparams("basic", history=8, horizon=12, transformer=TINY_TR)
+    hp.update(HP)
+    env = types.SimpleNamespace(NodeType=["VEHICLE"], get_edge_types=lambda: [], robot_type=None)
+    reg = ModelRegistrar("/tmp", dev)
+    tr = Trajectron(reg, hp, None, dev, get_timesteps_data=get_timesteps_data)
+    tr.set_environment(env)
+    apply_recipe(reg.model_dict, seed=3)
+    ts = np.arange(10, 14)
+    hist, _ = tr.predict(scene, ts, 12, min_future_timesteps=12, min_history_timesteps=1)
+    want = compute_batch_statistics(hist, 0.5, max_hl=8, ph=12, node_type_enum=["VEHICLE"])["VEHICLE"]
+    got = tr.evaluate(scene, ts, 12, min_history_timesteps=1)["VEHICLE"]
+    assert len(got["ade"]) == len(want["ade"]) > 0
+    assert np.max(np.abs(got["ade"] - np.array(want["ade"]))) <= 1e-3 and np.max(np.abs(got["fde"] - np.array(want["fde"]))) <= 1e-3

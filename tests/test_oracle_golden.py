@@ -144,3 +144,22 @@ def test_lane_batch_oracle_matches_reference_outputs():
             assert np.array_equal(pts, zl[f"{tag}::lane_input"][i])
             assert np.array_equal(label, zl[f"{tag}::lane_label"][i])
             assert np.array_equal(mask, zl[f"{tag}::lane_t_mask"][i])
+
+
+def test_batch_statistics_oracle_matches_reference_outputs():
+    """oracle/batch.py::batch_statistics == compute_batch_statistics / lane_compute_batch_statistics of the reference on the same
+    synthetic prediction dicts (tests/golden/evalstats.npz)."""
+    import os
+    from oracle import batch as ob
+    GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(GOLD, "batch.npz"))
+    ze = np.load(os.path.join(GOLD, "evalstats.npz"))
+    off = np.concatenate([[0], np.cumsum(z["lengths"])])
+    futures = []
+    for n, t in zip(ze["nodes"], ze["timesteps"]):
+        rows = z["table"][off[n]:off[n + 1]]
+        futures.append(rows[t + 1 - z["first"][n]: t + 13 - z["first"][n], 0:2])
+    ade, fde = ob.batch_statistics(list(ze["pred"]), futures)
+    assert np.allclose(ade, ze["ade"], rtol=0, atol=1e-12) and np.allclose(fde, ze["fde"], rtol=0, atol=1e-12)
+    ade, fde = ob.batch_statistics(list(ze["lane_pred"]), futures)
+    assert np.allclose(ade, ze["lane_ade"], rtol=0, atol=1e-12) and np.allclose(fde, ze["lane_fde"], rtol=0, atol=1e-12)
