@@ -1056,6 +1056,7 @@ struct FusedArgs {
   float *part[2], *xres[2], *selfkv, *memkv;
   unsigned *sync;                              // [0]: time-out word; [32 * (1 + cluster)]: arrival counter
   int nlayers;
+  int test_stall;                              // fault injection (MMT_TEST_FUSED_STALL=1, tests only): one workgroup walks away
 };
 
 // the per-phase fields of the argument block; everything else stays as the host filled it in
@@ -1109,6 +1110,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_fused4_kernel(FusedArgs f) {
   for (int s = 0; s < ph; ++s) {
 #pragma clang loop unroll(disable)
     for (int l = 0; l < L; ++l) {
+      if (f.test_stall && p == 15 && cluster == 0 && g == 1) return;      // its cluster must time out, the call must turn NaN
       fused_set_phase<PH_A>(a, f, s, l, p);
       bool ok;
       if (l > 0) ok = phase4_body<DH, CPW, PH_A, XM_REDUCE, true>(a, cluster, g, smem, fs);
@@ -1404,6 +1406,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       f.memkv = memkv;
       f.sync = sync;
       f.nlayers = L;
+      f.test_stall = getenv("MMT_TEST_FUSED_STALL") ? 1 : 0;
       hipLaunchKernelGGL((mmt_dec_fused4_kernel<DH, CPW>), grid, blk, lds_a, st, f);
       p = 3 * L * ph;
       a.tmo = sync;

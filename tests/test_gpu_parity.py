@@ -230,6 +230,32 @@ def test_fused_decoder_is_bit_identical_to_launch_per_phase():
             torch.cuda.synchronize()
 
 
+def test_fused_decoder_times_out_loudly(monkeypatch):
+    """Fault injection: one workgroup of cluster 0 leaves the fused kernel early (MMT_TEST_FUSED_STALL), so its siblings can
+    never complete their wait.  Every wait is bounded: the launch ends (0.2 s), the time-out word makes the final head launch
+    return NaN for the WHOLE call (never stale numbers), and the next call is clean again."""
+    import time
+    from multimodal_transformer_amd import ops
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=12)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    x, x_st, *_ = _to(make_batch(64, 8, 12, seed=2), dev)
+    ops.decoder_select("cluster")
+    want, _ = model.predict(x, x_st, None, None, None, 12)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MMT_TEST_FUSED_STALL", "1")
+    t0 = time.perf_counter()
+    bad, _ = model.predict(x, x_st, None, None, None, 12)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isnan(bad).all()
+    assert 0.1 < dt < 5.0
+    monkeypatch.delenv("MMT_TEST_FUSED_STALL")
+    again, _ = model.predict(x, x_st, None, None, None, 12)
+    assert torch.equal(want, again)
+
+
 def test_large_batch_properties():
     """BASELINE config 5 size on one GPU (8192/8 = 1024 agents): finite, and rows equal the B=128 run."""
     dev = _dev()
