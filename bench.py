@@ -304,6 +304,23 @@ def main():
                          "achieved_gbs_vs_hbm": dec_bytes / (kt["decoder_ms"] * 1e-3) / 1e9, "hbm_peak_gbs": 8000.0},
             "kernels_ms": kt,
         }
+        # every kernel of the predict against both roofs (SURVEY.md section 8d figures; north star: HBM GB/s for the attention /
+        # decoder / head kernels, MFMA utilisation for the map encoders): algorithmic FLOPs and bytes per launch / measured time
+        n_enc_par = sum(p.numel() for k, m in reg.model_dict.items() if "node_history_encoder" in k for p in m.parameters()
+                        if p.dim() < 3)
+        enc_bytes = 4.0 * (n_enc_par + B * (args.history + 1) * (8 + hp["transformer"]["in_dim"]))
+        kr = {"encoder": {"ms": kt["encoder_ms"], "flop": MFLOP_ENCODER * 1e6 * B, "bytes": enc_bytes},
+              "decoder+head": {"ms": kt["decoder_ms"], "flop": dec_flops, "bytes": dec_bytes}}
+        if "map_encoder_ms" in kt:
+            n_map_par = sum(p.numel() for k, m in reg.model_dict.items() if "map_encoder" in k for p in m.parameters())
+            kr["map_encoder"] = {"ms": kt["map_encoder_ms"], "flop": (MFLOP_CNN if args.mode == "map_cnn" else 179.4) * 1e6 * B,
+                                 "bytes": 4.0 * (n_map_par + B * 3 * 100 * 100 + B * 32)}
+        for v in kr.values():
+            v["tflops"] = v["flop"] / (v["ms"] * 1e-3) / 1e12
+            v["mfma_f32_frac"] = v["tflops"] / PEAK_F32_MFMA_TFLOPS
+            v["gbs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            v["hbm_frac"] = v["gbs"] / 8000.0
+        line["kernel_rooflines"] = kr
         if args.sweep and not distributed:
             sweep = {}
             for bb in (1024, 4096):
