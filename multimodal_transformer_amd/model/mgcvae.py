@@ -110,12 +110,27 @@ class MultimodalGenerativeCVAE(object):
         """mgcvae.py:231-308.  Returns the same 7-tuple; the causal mask slot is None because the kernels
         rebuild it, the padding mask is the uint8 (B,T) tensor the encoder kernel derived."""
         hp = self.hyperparams
-        memory, pad = self._m("node_history_encoder").forward_with_mask(inputs_st)
         encoded_map = encoded_lane = None
+        side = None
         if hp["map_cnn_encoding"] or hp["map_vit_encoding"]:
             if mode == ModeKeys.TRAIN:
                 raise MmtError("training-mode dropout on the map feature is not implemented in the HIP path")
-            encoded_map = self._m("map_encoder").forward_raw(map)
+            # The map encoder does not depend on the history encoder, and each of them runs one workgroup per agent (tile): at the
+            # benchmark batch (128 agents, 256 CUs) they fit on the chip side by side.  Fork to a second stream, join before the decode.
+            if map.is_cuda:
+                cur = torch.cuda.current_stream(map.device)
+                side = self.__dict__.get("_side_stream") or torch.cuda.Stream(map.device)
+                self.__dict__["_side_stream"] = side
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    encoded_map = self._m("map_encoder").forward_raw(map)
+                map.record_stream(side)
+            else:
+                encoded_map = self._m("map_encoder").forward_raw(map)      # (raises: no CPU path)
+        memory, pad = self._m("node_history_encoder").forward_with_mask(inputs_st)
+        if side is not None:
+            torch.cuda.current_stream(map.device).wait_stream(side)
+            encoded_map.record_stream(torch.cuda.current_stream(map.device))
         elif hp["lane_cnn_encoding"]:
             B = inputs.shape[0]
             ln, sn = hp["max_lane_num"], hp["sample_num"]

@@ -498,7 +498,8 @@ _ws_cache = {}
 
 
 def _workspace(nfloats, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream): kernels of two streams (the map encoder runs beside the history encoder) never share scratch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(int(nfloats * 1.25) + 1024, dtype=torch.float32, device=device)
