@@ -13,7 +13,9 @@
 #ifdef MMT_PROFILE
 __device__ unsigned long long g_prof[512];
 #define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && s == (ph / 2)) g_prof[L * 16 + (k)] = clock64(); } while (0)
+#define ESTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[256 + L * 8 + (k)] = wall_clock64(); } while (0)
 #else
+#define ESTAMP(k) do { } while (0)
 #define STAMP(k) do { } while (0)
 #endif
 
@@ -102,8 +104,10 @@ __global__ __launch_bounds__(MMT_NT) void mmt_encoder_kernel(mmt_encoder E, EncL
   const float scale = 1.0f / sqrtf((float)dh);
   for (int L = 0; L < E.nlayers; ++L) {
     const mmt_enc_layer &W = E.layer[L];
+    ESTAMP(0);
     linear_to_lds<MB, EPI_STORE, true>(xs, ldx, W.qkv, buf, ldb, pre, next_of(W.out));
     __syncthreads();
+    ESTAMP(1);
     for (int g = tid >> 4; g < nrows * H; g += nt >> 4) {
       const int r = g / H, h = g - r * H, a = r / T, t = r - a * T;
       float *q = buf + r * ldb + h * dh;
@@ -111,17 +115,23 @@ __global__ __launch_bounds__(MMT_NT) void mmt_encoder_kernel(mmt_encoder E, EncL
       attend_group<DH>(q, kb, kb + d, ldb, t + 1, padbits[a], scale, q);   // causal: keys 0..t
     }
     __syncthreads();
+    ESTAMP(2);
     linear_to_lds<MB, EPI_ADD, true>(buf, ldb, W.out, xs, ldx, pre, next_of(W.ff1));
     __syncthreads();
+    ESTAMP(3);
     layer_norm_rows<false>(xs, ldx, nrows, d, W.ln1);
     __syncthreads();
+    ESTAMP(4);
     linear_to_lds<MB, EPI_RELU, true>(xs, ldx, W.ff1, buf, ldb, pre, next_of(W.ff2));
     __syncthreads();
+    ESTAMP(5);
     linear_to_lds<MB, EPI_ADD, true>(buf, ldb, W.ff2, xs, ldx, pre,
                                      L + 1 < E.nlayers ? next_of(E.layer[L + 1].qkv) : no_next());
     __syncthreads();
+    ESTAMP(6);
     layer_norm_rows<false>(xs, ldx, nrows, d, W.ln2);
     __syncthreads();
+    ESTAMP(7);
   }
   for (int i = tid; i < nrows * d; i += nt) {
     const int r = i / d, c = i - r * d;

@@ -29,3 +29,10 @@ for L in range(6):
     st = [buf[L * 16 + k] for k in range(13)]
     d = [st[i + 1] - st[i] for i in range(12)]
     print(f"layer {L}: total {st[12] - st[0]:7d} cyc | " + " ".join(f"{n}={v}" for n, v in zip(names, d)))
+
+# history encoder (workgroup 0): wall-clock (100 MHz) stamps per layer
+names = ["qkv", "attention", "out-proj", "ln1", "ff1", "ff2", "ln2"]
+for L in range(6):
+    st = [buf[256 + L * 8 + k] for k in range(8)]
+    d = [(st[i + 1] - st[i]) / 100.0 for i in range(7)]
+    print(f"encoder layer {L}: total {(st[7] - st[0]) / 100.0:6.2f} us | " + " ".join(f"{n}={v:.2f}" for n, v in zip(names, d)))
