@@ -256,6 +256,29 @@ def test_fused_decoder_times_out_loudly(monkeypatch):
     assert torch.equal(want, again)
 
 
+def test_teacher_forced_decoder_full_width_agrees_across_kernel_families():
+    """Trajectory_Decoder.forward (teacher-forced, Transformer_model.py:168-199) at the shipped width: the fused one-launch form ==
+    the launch-per-phase form bit for bit, and both agree with the persistent kernel (different summation order) to 1e-5."""
+    from multimodal_transformer_amd import ops
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=12)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    for B in (128, 37):
+        b = make_batch(B, 8, 12, seed=3)
+        x_st, y_st = torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev)
+        memory, pad = reg.model_dict["VEHICLE/node_history_encoder"].forward_with_mask(x_st)
+        tgt = torch.cat([torch.zeros(B, 1, 2, device=dev), y_st[:, :-1]], dim=1).contiguous()
+        dec = reg.model_dict["VEHICLE/decoder/transformer_decoder"]
+        out = {}
+        for impl in ("cluster", "cluster_launches", "persistent"):
+            ops.decoder_select(impl)
+            out[impl] = dec(tgt, memory, None, None, pad.bool())
+        assert torch.isfinite(out["cluster"]).all()
+        assert torch.equal(out["cluster"], out["cluster_launches"])
+        assert rel_err(out["cluster"].cpu().numpy(), out["persistent"].cpu().numpy()) <= 1e-5
+
+
 def test_large_batch_properties():
     """BASELINE config 5 size on one GPU (8192/8 = 1024 agents): finite, and rows equal the B=128 run."""
     dev = _dev()
