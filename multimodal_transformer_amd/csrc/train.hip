@@ -910,11 +910,12 @@ __global__ __launch_bounds__(256) void mmt_col2im_kernel(const float *__restrict
 
 // ------------------------------------------------------------------------------------------ loss / optimizer
 // dpos[t][b][:] = (pos - y) / ||pos - y|| / (B * ph)   with pos laid out [ph][B][2], y laid out [B][ph][2]
-__global__ void mmt_l2_loss_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ y, int B, int ph,
-                                       float *__restrict__ dpos, float *__restrict__ loss_sum) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// (with loss_sum: ONE block, fixed summation order - the same bits on every run, like mmt_finalize)
+__global__ __launch_bounds__(1024) void mmt_l2_loss_bwd_kernel(const float *__restrict__ pos, const float *__restrict__ y, int B, int ph,
+                                                               float *__restrict__ dpos, float *__restrict__ loss_sum) {
+  __shared__ float wsum[16];
   float contrib = 0.f;
-  if (idx < B * ph) {
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < B * ph; idx += gridDim.x * blockDim.x) {
     const int b = idx % B, t = idx / B;
     const float dx = pos[(size_t)idx * 2] - y[((size_t)b * ph + t) * 2];
     const float dy = pos[(size_t)idx * 2 + 1] - y[((size_t)b * ph + t) * 2 + 1];
@@ -922,12 +923,18 @@ __global__ void mmt_l2_loss_bwd_kernel(const float *__restrict__ pos, const floa
     const float w = n > 0.f ? 1.0f / (n * (float)B * (float)ph) : 0.f;
     dpos[(size_t)idx * 2] = dx * w;
     dpos[(size_t)idx * 2 + 1] = dy * w;
-    contrib = n / ((float)B * (float)ph);
+    contrib += n / ((float)B * (float)ph);
   }
   if (loss_sum) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, contrib);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float total = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += wsum[w];
+      *loss_sum += total;
+    }
   }
 }
 
@@ -1247,8 +1254,8 @@ extern "C" int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long 
 
 extern "C" int mmt_l2_loss_bwd(const float *pos, const float *y, int B, int ph, float *dpos, float *loss_sum, void *stream) {
   if (!pos || !y || !dpos || B <= 0 || ph <= 0) return mmt_set_error(MMT_EINVAL, "mmt_l2_loss_bwd: bad arguments");
-  hipLaunchKernelGGL(mmt_l2_loss_bwd_kernel, dim3((B * ph + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, y, B, ph, dpos,
-                     loss_sum);
+  hipLaunchKernelGGL(mmt_l2_loss_bwd_kernel, dim3(loss_sum ? 1 : (B * ph + 255) / 256), dim3(loss_sum ? 1024 : 256), 0,
+                     (hipStream_t)stream, pos, y, B, ph, dpos, loss_sum);
   return launch_ok("mmt_l2_loss_bwd");
 }
 

@@ -340,12 +340,15 @@ __global__ void mmt_pack_linear_kernel(const float *__restrict__ w, int n, int k
   }
 }
 
-__global__ void mmt_finalize_kernel(const float *__restrict__ pred_st, const float *__restrict__ node_pos,
-                                    const float *__restrict__ gt, int metres, int B, int ph, float *__restrict__ pred_m,
-                                    float *__restrict__ ade, float *__restrict__ fde, float *__restrict__ loss_sum) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  float mean_err = 0.f;
-  if (b < B) {
+// With loss_sum the host launches ONE block: every thread adds its agents in index order, the waves are reduced by a fixed
+// shuffle tree and summed in wave order - the same bits on every run (a float atomicAdd per wave is not).
+__global__ __launch_bounds__(1024) void mmt_finalize_kernel(const float *__restrict__ pred_st, const float *__restrict__ node_pos,
+                                                            const float *__restrict__ gt, int metres, int B, int ph,
+                                                            float *__restrict__ pred_m, float *__restrict__ ade,
+                                                            float *__restrict__ fde, float *__restrict__ loss_sum) {
+  __shared__ float wsum[16];
+  float mine = 0.f;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
     const float nx = node_pos ? node_pos[b * 2] : 0.f, ny = node_pos ? node_pos[b * 2 + 1] : 0.f;
     float acc = 0.f, last = 0.f;
     for (int t = 0; t < ph; ++t) {
@@ -362,15 +365,21 @@ __global__ void mmt_finalize_kernel(const float *__restrict__ pred_st, const flo
         acc += last;
       }
     }
-    mean_err = acc / (float)ph;
+    const float mean_err = acc / (float)ph;
     if (ade) ade[b] = mean_err;
     if (fde) fde[b] = last;
+    mine += mean_err;
   }
   if (loss_sum) {
-    float v = b < B ? mean_err : 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, v);
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float total = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += wsum[w];
+      *loss_sum += total;
+    }
   }
 }
 
@@ -582,7 +591,7 @@ extern "C" int mmt_finalize(const float *pred_st, const float *node_pos, const f
   if (!pred_st || B <= 0 || ph <= 0) return fail(MMT_EINVAL, "mmt_finalize: bad arguments");
   if ((pred_m || metric_in_metres) && !node_pos) return fail(MMT_EINVAL, "mmt_finalize: node_pos required for metres");
   if ((ade || fde || loss_sum) && !gt) return fail(MMT_EINVAL, "mmt_finalize: metrics need gt");
-  hipLaunchKernelGGL(mmt_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred_st, node_pos, gt,
-                     metric_in_metres, B, ph, pred_m, ade, fde, loss_sum);
+  hipLaunchKernelGGL(mmt_finalize_kernel, dim3(loss_sum ? 1 : (B + 255) / 256), dim3(loss_sum ? 1024 : 256), 0, (hipStream_t)stream,
+                     pred_st, node_pos, gt, metric_in_metres, B, ph, pred_m, ade, fde, loss_sum);
   return check_launch("mmt_finalize");
 }

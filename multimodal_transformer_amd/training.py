@@ -807,7 +807,7 @@ class Trainer:
     0.01), second parameter group 'map_encoder' at lr 8e-4, ``clip_grad_value_(hp.grad_clip)`` on the averaged
     gradient, ExponentialLR(hp.learning_decay_rate) stepped once per batch."""
 
-    def __init__(self, model, B, T, ph, use_graph=True, process_group=None, distributed=True):
+    def __init__(self, model, B, T, ph, use_graph=True, process_group=None, distributed=True, always_reduce=False):
         import torch.distributed as dist
         hp = model.hyperparams
         self.engine = TrainEngine(model, B, T, ph)
@@ -815,6 +815,9 @@ class Trainer:
         self.world = 1
         if distributed and dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size(process_group)
+        # always_reduce: issue the all-reduce even in a one-rank group (tools/rehearse_rccl.py: the RCCL call between the two graph
+        # replays on a single GPU)
+        self.always_reduce = bool(always_reduce) and dist.is_available() and dist.is_initialized()
         self.pg = process_group
         self.lr0 = float(hp["learning_rate"])
         self.gamma = float(hp["learning_decay_rate"]) if hp.get("learning_rate_style", "exp") == "exp" else 1.0
@@ -866,7 +869,7 @@ class Trainer:
             self._g_fb.replay()
         else:
             self._fwd_bwd()
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             import torch.distributed as dist
             dist.all_reduce(self.engine.flat_grad, group=self.pg)      # one flat fp32 bucket
         if self.use_graph:

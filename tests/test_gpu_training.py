@@ -510,6 +510,7 @@ def test_graph_replay_equals_eager_and_is_deterministic():
     for other in res[1:]:
         assert np.allclose(res[0][0], other[0], rtol=1e-6)
         assert torch.equal(res[1][1], other[1]) or other is res[1]
+    assert res[1][0] == res[2][0]                            # the reported loss too: one block sums it in a fixed order
     assert rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) <= 1e-6
 
 
@@ -634,3 +635,37 @@ def test_standalone_mlp_matches_reference_including_batch_dim_softmax():
     from multimodal_transformer_amd._lib import MmtError
     with pytest.raises(MmtError):
         m(torch.zeros(3, 32))            # CPU tensor: no fallback
+
+
+def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
+    """The multi-rank step on one GPU: a one-rank RCCL group, the flat gradient all-reduce issued eagerly between the two HIP-graph
+    replays (bench.py --gpus N runs exactly this with N ranks).  A one-rank sum changes nothing: losses and weights equal a run
+    without a group, bit for bit.  Last test of the file: it initialises torch.distributed for the process."""
+    import torch.distributed as dist
+    from multimodal_transformer_amd import training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _dev()
+
+    def run(reduce):
+        hp = make_hyperparams("basic", history=8, horizon=12)
+        model, reg = _model(hp, dev)
+        apply_recipe(reg.model_dict, seed=2)
+        tr = training.Trainer(model, 128, 9, 12, use_graph=True, always_reduce=reduce)
+        assert tr.always_reduce == reduce
+        losses = []
+        for it in range(4):
+            b = make_batch(128, 8, 12, seed=20 + it)
+            losses.append(float(tr.step(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev))))
+        return losses, torch.cat([p.detach().reshape(-1) for p in reg.parameters()]).clone()
+
+    plain = run(False)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+    try:
+        dist.barrier()
+        reduced = run(True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert plain[0] == reduced[0] and torch.equal(plain[1], reduced[1])
