@@ -207,7 +207,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # MMT_BENCH_FORCE_DIST=1: take the multi-rank branch (RCCL group, barriers, MAX over ranks) with one rank - a rehearsal on one GPU
+    distributed = world > 1 or os.environ.get("MMT_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and not distributed:
