@@ -30,6 +30,7 @@ class MultimodalGenerativeCVAE(object):
         self.curr_iter = 0
         self.node_modules = dict()
         self.lane_dedup = True      # see at_dec_lane
+        self.class_input = []       # mgcvae.py:419: per-lane decoder states for Lane/MLP_Softmax (train_decoder / test_decoder)
 
         self.min_hl = hyperparams["minimum_history_length"]
         self.max_hl = hyperparams["maximum_history_length"]
@@ -148,7 +149,7 @@ class MultimodalGenerativeCVAE(object):
         start = n_s_t0[:, 0:self.pred_state_length].contiguous()
         if hp["lane_cnn_encoding"]:
             return None, self.at_dec_lane(dec, head, memory, memory_key_padding_mask, start, lane_feature,
-                                          prediction_horizon)
+                                          prediction_horizon, keep_h=self.__dict__.get("_keep_class_input", False))
         fusion = self._m("fusion/hist_map") if map_feature is not None else None
         packed = dec.packed(head=head, map_fusion=fusion)
         pred, _ = ops.decoder_forward(packed, memory, memory_key_padding_mask, start, prediction_horizon,
@@ -181,7 +182,35 @@ class MultimodalGenerativeCVAE(object):
         reference's losses, :610-611 are commented out)."""
         return self._m("Lane/MLP_Softmax")(encoded_lane)
 
-    def at_dec_lane(self, dec, head, memory, pad, start, lane_feature, ph):
+    def train_decoder(self, autoregressive, memory, memory_mask, memory_key_padding_mask, labels_st, n_s_t0, encoded_lane,
+                      encoded_map, prediction_horizon):
+        """mgcvae.py:451-506: at_dec or non_at_dec, then (lane mode) Lane/MLP_Softmax on the concatenation of the lanes' decoder
+        states -> (history_pred, lane_pred, pred_lane_index).  ``predict`` / the losses skip this wrapper: the classification
+        output is dead in the reference (its loss term is commented out, :610-611), so they do not pay for it."""
+        self.class_input = []
+        self._keep_class_input = bool(self.hyperparams["lane_cnn_encoding"])
+        try:
+            if autoregressive:
+                history_pred, lane_pred = self.at_dec(memory, memory_mask, memory_key_padding_mask, n_s_t0, encoded_lane,
+                                                      encoded_map, prediction_horizon)
+            else:
+                history_pred, lane_pred = self.non_at_dec(memory, memory_mask, memory_key_padding_mask, labels_st, n_s_t0,
+                                                          encoded_lane, encoded_map, prediction_horizon)
+        finally:
+            self._keep_class_input = False
+        pred_lane_index = None
+        if self.hyperparams["lane_cnn_encoding"]:
+            pred_lane_index = self.classification_lane(torch.cat(self.class_input, dim=-1).contiguous())
+            self.class_input = []
+        return history_pred, lane_pred, pred_lane_index
+
+    def test_decoder(self, autoregressive, memory, memory_mask, memory_key_padding_mask, n_s_t0, encoded_lane, encoded_map,
+                     prediction_horizon):
+        """mgcvae.py:508-550: always autoregressive (the flag is ignored there too)."""
+        return self.train_decoder(True, memory, memory_mask, memory_key_padding_mask, None, n_s_t0, encoded_lane, encoded_map,
+                                  prediction_horizon)
+
+    def at_dec_lane(self, dec, head, memory, pad, start, lane_feature, ph, keep_h=False):
         """Lane branch (mgcvae.py:395-424).  The reference overwrites ``lane_feature`` inside its lane loop
         (:404), so lanes 1 and 2 are decoded with lane 0's feature and -- dropout off -- are bit-identical to
         lane 0.  ``lane_dedup`` (default) launches the decode once and returns the result three times;
@@ -195,8 +224,10 @@ class MultimodalGenerativeCVAE(object):
         outs = []
         for i in range(n_lane):
             if i == 0 or not self.lane_dedup:
-                pred, _ = ops.decoder_forward(packed, memory, pad, start, ph, mem_feat=feat0)
+                pred, h = ops.decoder_forward(packed, memory, pad, start, ph, mem_feat=feat0, want_h=keep_h)
             outs.append(pred)
+            if keep_h:          # mgcvae.py:418-419: the decoder states of the last step's full pass = the states of every step
+                self.class_input.append(h)
         return outs
 
     # ------------------------------------------------------------------ public entry points

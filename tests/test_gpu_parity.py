@@ -279,6 +279,54 @@ def test_teacher_forced_decoder_full_width_agrees_across_kernel_families():
         assert rel_err(out["cluster"].cpu().numpy(), out["persistent"].cpu().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("tiny", [True, False])
+def test_train_and_test_decoder_wrappers_match_oracle(tiny):
+    """train_decoder / test_decoder (mgcvae.py:451-550): the dispatch wrappers with the reference's signatures.  Lane mode adds
+    Lane/MLP_Softmax on the concatenated per-lane decoder states (softmax over the batch axis, MLP.py:18-21) - checked against the
+    oracle's ar_decode(keep_h) + _classify (the positions are pinned by the predict goldens; the classification output has no
+    fixture in the reference: parity unpinned beyond the stand-alone Mlp golden)."""
+    from oracle import reference_form as rf     # checker only
+    from multimodal_transformer_amd.model.model_utils import ModeKeys
+    dev = _dev()
+    z, _ = load_golden(("tiny_" if tiny else "full_") + "lane_cnn")
+    hp, B, ph = hp_for("lane_cnn", tiny)
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, tiny, z)
+    batch = batch_for("lane_cnn", tiny)
+    x, x_st, y, y_st, lanes, maps = _to(batch, dev)
+    memory, _, pad, n0, node_pos, enc_lane, enc_map = model.obtain_encoded_tensors(ModeKeys.EVAL, x, x_st, lanes, maps)
+    hist, lane, idx = model.test_decoder(True, memory, None, pad, n0, enc_lane, enc_map, ph)
+    hist2, lane2, idx2 = model.train_decoder(True, memory, None, pad, y_st, n0, enc_lane, enc_map, ph)
+    assert hist is None and hist2 is None and len(lane) == 3 and idx.shape == (B, ph, 3)
+    assert torch.equal(idx, idx2) and all(torch.equal(a, b) for a, b in zip(lane, lane2))
+    assert model.class_input == []
+    ref = rf.ReferenceFormModel(hp)
+    set_weights(ref.m, tiny, z)
+    ref.m.eval()
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    with torch.no_grad():
+        mem, cm, rpad, rn0, _, rlane, _ = ref.encode(t["x"], t["x_st"], t["lanes"], None, train=False)
+        keep = []
+        _, want_lane = ref.ar_decode(mem, cm, rpad, rn0, rlane, None, ph, keep)
+        want_idx = ref._classify(keep)
+    for got, want in zip(lane, want_lane):
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= TOL
+    assert rel_err(idx.cpu().numpy(), want_idx.numpy()) <= TOL
+    assert np.allclose(idx.sum(dim=0).cpu().numpy(), 1.0, atol=1e-5)
+    # Basic mode: no classification, the wrappers only dispatch
+    hp_b, Bb, _ = hp_for("basic", True)
+    mb, rb = _model(hp_b, dev)
+    zb, _ = load_golden("tiny_basic")
+    set_weights(rb.model_dict, True, zb)
+    xb, xb_st, yb, yb_st, _, _ = _to(batch_for("basic", True), dev)
+    memory, _, pad, n0, _, _, _ = mb.obtain_encoded_tensors(ModeKeys.EVAL, xb, xb_st, None, None)
+    h_ar, l_ar, i_ar = mb.test_decoder(False, memory, None, pad, n0, None, None, ph)
+    h_tf, _, i_tf = mb.train_decoder(False, memory, None, pad, yb_st, n0, None, None, ph)
+    assert i_ar is None and i_tf is None and l_ar == []
+    assert torch.equal(h_ar, mb.at_dec(memory, None, pad, n0, None, None, ph)[0])
+    assert torch.equal(h_tf, mb.non_at_dec(memory, None, pad, yb_st, n0, None, None, ph)[0])
+
+
 def test_large_batch_properties():
     """BASELINE config 5 size on one GPU (8192/8 = 1024 agents): finite, and rows equal the B=128 run."""
     dev = _dev()
