@@ -321,6 +321,9 @@ int mmt_lr_step(float *state_dev, float gamma, void *stream);
 int mmt_softmax_axis(const float *x, long outer, int n, long inner, float *y, void *stream);
 /* torch.cumsum over the middle axis: mlp(h).cumsum(dim=-2) of non_at_dec (mgcvae.py:352,370) */
 int mmt_cumsum_axis(const float *x, long outer, int n, long inner, float *y, void *stream);
+/* L2_norm (model_utils.py:154-160): out[r] = ||a[r] - b[rb]||_2 over the last axis of length n; b is broadcast over a middle axis
+ * of length rep (a: (outer, rep, inner, n), b: (outer, inner, n)); rep = 1 for equal shapes */
+int mmt_l2_norm(const float *a, const float *b, long rows, int n, long rep, long inner, float *out, void *stream);
 /* y += x (gradient of that cumsum walked backwards in time) */
 int mmt_add_inplace(float *y, const float *x, long n, void *stream);
 

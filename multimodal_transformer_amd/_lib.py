@@ -152,6 +152,7 @@ SIGNATURES = {
     "mmt_lr_step": (C.c_int, [fptr, C.c_float, C.c_void_p]),
     "mmt_softmax_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
     "mmt_cumsum_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
+    "mmt_l2_norm": (C.c_int, [fptr, fptr, C.c_long, C.c_int, C.c_long, C.c_long, fptr, C.c_void_p]),
     "mmt_add_inplace": (C.c_int, [fptr, fptr, C.c_long, C.c_void_p]),
     "mmt_patchify": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, fptr, C.c_long, C.c_void_p]),
     "mmt_gelu_fwd": (C.c_int, [fptr, fptr, C.c_long, C.c_void_p]),

@@ -368,6 +368,30 @@ def cumsum_axis(x, y, axis):
     _lib.check(lib.mmt_cumsum_axis(_p(x), outer, x.shape[axis], inner, _p(y), _stream()), "mmt_cumsum_axis")
 
 
+def l2_norm(a, b):
+    """torch.norm(a - b, p=2, dim=-1) for contiguous fp32 device tensors; ``b`` has a's shape, or a's shape with ONE axis (not the
+    last) of length 1 that is broadcast (model_utils.L2_norm's call shapes)."""
+    if a.dim() != b.dim() or a.shape[-1] != b.shape[-1]:
+        raise MmtError(f"l2_norm: shapes {tuple(a.shape)} and {tuple(b.shape)} do not line up")
+    diff = [i for i in range(a.dim() - 1) if a.shape[i] != b.shape[i]]
+    if len(diff) > 1 or (diff and b.shape[diff[0]] != 1):
+        raise MmtError(f"l2_norm: {tuple(b.shape)} must equal {tuple(a.shape)} up to one broadcast axis of length 1")
+    _contig2(a, "a", a.shape), _contig2(b, "b", b.shape)
+    rep, inner = 1, 1
+    if diff:
+        rep = a.shape[diff[0]]
+        for s_ in a.shape[diff[0] + 1:-1]:
+            inner *= s_
+    else:
+        for s_ in a.shape[:-1]:
+            inner *= s_
+    rows = a.numel() // a.shape[-1]
+    out = torch.empty(a.shape[:-1], dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    _lib.check(lib.mmt_l2_norm(_p(a), _p(b), rows, a.shape[-1], rep, inner, _p(out), _stream()), "mmt_l2_norm")
+    return out
+
+
 def add_inplace(y, x):
     """y += x (contiguous, same shape)."""
     _contig2(y, "y", y.shape), _contig2(x, "x", y.shape)

@@ -1000,6 +1000,21 @@ __global__ void mmt_cumsum_axis_kernel(const float *__restrict__ x, long outer, 
   }
 }
 
+// out[r] = || a[r][:] - b[rb][:] ||_2 with rb = (r / (rep * inner)) * inner + r % inner: b is broadcast over a middle axis of
+// length rep (L2_norm(lane_pred (bs,L,T,2), labels (bs,1,T,2)), model_utils.py:154-160; rep = 1: equal shapes)
+__global__ void mmt_l2_norm_kernel(const float *__restrict__ a, const float *__restrict__ b, long rows, int n, long rep, long inner,
+                                   float *__restrict__ out) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const long rb = (r / (rep * inner)) * inner + r % inner;
+    float s = 0.f;
+    for (int c = 0; c < n; ++c) {
+      const float d = a[r * n + c] - b[rb * n + c];
+      s += d * d;
+    }
+    out[r] = sqrtf(s);
+  }
+}
+
 __global__ void mmt_add_inplace_kernel(float *__restrict__ y, const float *__restrict__ x, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += x[i];
@@ -1294,6 +1309,14 @@ extern "C" int mmt_cumsum_axis(const float *x, long outer, int n, long inner, fl
   hipLaunchKernelGGL(mmt_cumsum_axis_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, outer, n,
                      inner, y);
   return launch_ok("mmt_cumsum_axis");
+}
+
+extern "C" int mmt_l2_norm(const float *a, const float *b, long rows, int n, long rep, long inner, float *out, void *stream) {
+  if (!a || !b || !out || rows <= 0 || n <= 0 || rep <= 0 || inner <= 0 || rows % (rep * inner))
+    return mmt_set_error(MMT_EINVAL, "mmt_l2_norm: bad arguments (rows %ld must be a multiple of rep %ld x inner %ld)", rows, rep, inner);
+  hipLaunchKernelGGL(mmt_l2_norm_kernel, dim3((unsigned)std::min<long>((rows + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, a,
+                     b, rows, n, rep, inner, out);
+  return launch_ok("mmt_l2_norm");
 }
 
 extern "C" int mmt_patchify(const float *img, int B, int C, int S, int P, float alpha, float beta, float *out, long ld, void *stream) {

@@ -23,3 +23,10 @@ def generate_square_subsequent_mask(sz, device):
 def generate_mask(src):
     """Key-padding mask: NaN in feature column 1 (model_utils.py:148-151)."""
     return torch.isnan(src)[:, :, 1]
+
+
+def L2_norm(y_pred, labels):
+    """model_utils.py:154-160: ``torch.norm(y_pred - labels, p=2, dim=-1)`` on the device (``mmt_l2_norm``); ``labels`` may carry one
+    broadcast axis of length 1, as in the lane loss (mgcvae.py:603-606).  The losses themselves use the fused ``mmt_finalize``."""
+    from .. import _train_kernels as K
+    return K.l2_norm(y_pred.contiguous(), labels.contiguous())

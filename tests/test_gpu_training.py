@@ -637,6 +637,24 @@ def test_standalone_mlp_matches_reference_including_batch_dim_softmax():
         m(torch.zeros(3, 32))            # CPU tensor: no fallback
 
 
+def test_l2_norm_matches_torch_norm_including_the_lane_broadcast():
+    """model_utils.L2_norm (model_utils.py:154-160) on mmt_l2_norm: equal shapes, and the lane loss's (bs,L,T,2) vs (bs,1,T,2)."""
+    from multimodal_transformer_amd._lib import MmtError
+    from multimodal_transformer_amd.model.model_utils import L2_norm
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for sa, sb in (((37, 12, 2), (37, 12, 2)), ((37, 3, 12, 2), (37, 1, 12, 2)), ((5, 3, 12, 2), (5, 3, 12, 2)), ((1, 2), (1, 2)),
+                   ((4, 7, 3), (1, 7, 3))):
+        a, b = torch.randn(sa, generator=g) * 3, torch.randn(sb, generator=g) * 3
+        got = L2_norm(a.to(dev), b.to(dev))
+        want = torch.norm(a - b, p=2, dim=-1)
+        assert got.shape == want.shape and rel_err(got.cpu().numpy(), want.numpy()) <= 1e-6
+    with pytest.raises(MmtError):
+        L2_norm(torch.zeros(4, 3, 12, 2, device=dev), torch.zeros(1, 1, 12, 2, device=dev))     # two broadcast axes
+    with pytest.raises(MmtError):
+        L2_norm(torch.zeros(4, 2), torch.zeros(4, 2))                                               # no CPU path
+
+
 def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
     """The multi-rank step on one GPU: a one-rank RCCL group, the flat gradient all-reduce issued eagerly between the two HIP-graph
     replays (bench.py --gpus N runs exactly this with N ranks).  A one-rank sum changes nothing: losses and weights equal a run
