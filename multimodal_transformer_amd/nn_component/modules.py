@@ -73,6 +73,13 @@ class Encoder(_PackedMixin, nn.Module):
         self.output_fc = nn.Linear(in_dim if low_dim == "sum" else in_dim * ntimestep, noutput)  # unused, in ckpt
         self.nhead = nhead
 
+    def init_weights(self) -> None:
+        """Transformer_model.py:38-43 (never called by the reference's constructors: the call is commented out there)."""
+        torch.nn.init.zeros_(self.input_fc.bias)
+        torch.nn.init.xavier_normal_(self.input_fc.weight)
+        torch.nn.init.zeros_(self.output_fc.bias)
+        torch.nn.init.xavier_normal_(self.output_fc.weight)
+
     def _nhead(self):
         return getattr(self, "nhead", None) or self.transformer_encoder.layers[0].self_attn.num_heads
 
@@ -103,6 +110,13 @@ class Decoder(_PackedMixin, nn.Module):
         self.transformer_decoder = nn.TransformerDecoder(layer, nlayers)      # parameter holder only
         self.output_fc = nn.Linear(in_dim, noutput)
         self.nhead = nhead
+
+    def init_weights(self) -> None:
+        """Transformer_model.py:83-89 (never called by the reference's constructors: the call is commented out there)."""
+        torch.nn.init.zeros_(self.input_fc.bias)
+        torch.nn.init.xavier_normal_(self.input_fc.weight)
+        torch.nn.init.zeros_(self.output_fc.bias)
+        torch.nn.init.xavier_normal_(self.output_fc.weight)
 
 
 class Trajectory_Decoder(Decoder):
