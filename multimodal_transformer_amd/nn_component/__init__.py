@@ -5,8 +5,8 @@ The classes own parameters only.  Their ``forward`` methods launch the hand-writ
 kernels through ``multimodal_transformer_amd.ops``; nothing is ever computed by ATen, and a CPU
 tensor or a missing libmmt_amd.so raises ``MmtError``.
 """
-from .modules import (CNNMapEncoder, Decoder, Encoder, Lane_Encoder, Mlp, PositionalEncoding,  # noqa: F401
+from .modules import (CNNMapEncoder, Decoder, Encoder, Lane_Decoder, Lane_Encoder, Mlp, PositionalEncoding,  # noqa: F401
                       Trajectory_Decoder, ViT)
 
-__all__ = ["CNNMapEncoder", "Decoder", "Encoder", "Lane_Encoder", "Mlp", "PositionalEncoding",
+__all__ = ["CNNMapEncoder", "Decoder", "Encoder", "Lane_Decoder", "Lane_Encoder", "Mlp", "PositionalEncoding",
            "Trajectory_Decoder", "ViT"]

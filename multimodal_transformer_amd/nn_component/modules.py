@@ -55,7 +55,19 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", pe)
 
     def forward(self, x):
-        raise MmtError("PositionalEncoding is fused into the encoder/decoder kernels and is not callable on its own")
+        """x (..., L, d) + pe[:L] (Transformer_model.py:126-129), dropout-free.  The encoder / decoder kernels add the table
+        themselves; this stand-alone form is two strided copy launches (``mmt_copy3``)."""
+        from .. import _train_kernels as K
+        if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != torch.float32 or x.dim() < 2:
+            raise MmtError("PositionalEncoding.forward needs a float32 device tensor (..., L, d) (no CPU fallback)")
+        L, d = x.shape[-2], x.shape[-1]
+        if L > self.pe.shape[0] or d != self.pe.shape[1] or x.numel() == 0:
+            raise MmtError(f"PositionalEncoding.forward: {L} positions x {d} features against a {tuple(self.pe.shape)} table")
+        src = x.contiguous().view(-1, L, d)
+        y = torch.empty_like(src)
+        K.copy3(src, y)
+        K.copy3(self.pe[:L].unsqueeze(0).expand(src.shape[0], L, d), y, accumulate=True)
+        return y.view(x.shape)
 
 
 class Encoder(_PackedMixin, nn.Module):
@@ -117,6 +129,71 @@ class Decoder(_PackedMixin, nn.Module):
         torch.nn.init.xavier_normal_(self.input_fc.weight)
         torch.nn.init.zeros_(self.output_fc.bias)
         torch.nn.init.xavier_normal_(self.output_fc.weight)
+
+
+class Lane_Decoder(Decoder):
+    """Transformer_model.py:132-152 (exported by the reference's nn_component, instantiated nowhere): a decoder pass WITHOUT a
+    target mask - every lane token attends to all lane tokens, then to the history memory.  Not on the hot path, so it runs on
+    the whole-batch kernels (``mmt_gemm`` / ``mmt_attention_fwd`` / ``mmt_layernorm_fwd``), dropout-free."""
+
+    def __init__(self, ninp, in_dim, nhead, fdim, nlayers, noutput):
+        super().__init__(nlayers, ninp, in_dim, nhead, fdim, noutput)
+
+    def forward(self, tgt, memory, memory_key_padding_mask=None):
+        from .. import _train_kernels as K
+        for t, name in ((tgt, "tgt"), (memory, "memory")):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3:
+                raise MmtError(f"Lane_Decoder.forward: {name} must be a float32 device tensor (B, L, features) (no CPU fallback)")
+        B, Lq, _ = tgt.shape
+        T, d = memory.shape[1], self.input_fc.weight.shape[0]
+        H = self.nhead
+        if memory.shape[0] != B or memory.shape[2] != d or B == 0 or Lq == 0 or T == 0:
+            raise MmtError(f"Lane_Decoder.forward: tgt {tuple(tgt.shape)} / memory {tuple(memory.shape)} do not line up with d_model {d}")
+        dev = tgt.device
+        new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        pad = None
+        if memory_key_padding_mask is not None:
+            pad = memory_key_padding_mask.to(torch.uint8).contiguous()
+        scale = 1.0 / math.sqrt(d // H)
+        M = B * Lq
+        u = new(M, d)
+        K.gemm(tgt.contiguous().view(M, -1), self.input_fc.weight.t(), u, bias=self.input_fc.bias)
+        x = self.pos_encoder(u.view(B, Lq, d)).view(M, d)
+        mem = memory.contiguous().view(B * T, d)
+
+        def add_norm(sub, res, ln):
+            y = new(M, d)
+            K.layernorm_fwd(sub, res, ln.weight, ln.bias, y, new(M, d), new(M))
+            return y
+
+        for layer in self.transformer_decoder.layers:
+            sa, ca = layer.self_attn, layer.multihead_attn
+            qkv = new(M, 3 * d)
+            K.gemm(x, sa.in_proj_weight.t(), qkv, bias=sa.in_proj_bias)
+            q3 = qkv.view(B, Lq, 3 * d)
+            o = new(B, Lq, d)
+            K.attention_fwd(q3[:, :, 0:d], q3[:, :, d:2 * d], q3[:, :, 2 * d:], o, new(B, H, Lq, Lq), H, scale)
+            sub = new(M, d)
+            K.gemm(o.view(M, d), sa.out_proj.weight.t(), sub, bias=sa.out_proj.bias)
+            x = add_norm(sub, x, layer.norm1)
+            q = new(M, d)
+            K.gemm(x, ca.in_proj_weight[:d].t(), q, bias=ca.in_proj_bias[:d].contiguous())
+            kv = new(B * T, 2 * d)
+            K.gemm(mem, ca.in_proj_weight[d:].t(), kv, bias=ca.in_proj_bias[d:].contiguous())
+            kv3 = kv.view(B, T, 2 * d)
+            o = new(B, Lq, d)
+            K.attention_fwd(q.view(B, Lq, d), kv3[:, :, 0:d], kv3[:, :, d:], o, new(B, H, Lq, T), H, scale, pad=pad)
+            sub = new(M, d)
+            K.gemm(o.view(M, d), ca.out_proj.weight.t(), sub, bias=ca.out_proj.bias)
+            x = add_norm(sub, x, layer.norm2)
+            hid = new(M, layer.linear1.weight.shape[0])
+            K.gemm(x, layer.linear1.weight.t(), hid, bias=layer.linear1.bias, relu=True)
+            sub = new(M, d)
+            K.gemm(hid, layer.linear2.weight.t(), sub, bias=layer.linear2.bias)
+            x = add_norm(sub, x, layer.norm3)
+        out = new(M, self.output_fc.weight.shape[0])
+        K.gemm(x, self.output_fc.weight.t(), out, bias=self.output_fc.bias)
+        return out.view(B, Lq, -1)
 
 
 class Trajectory_Decoder(Decoder):

@@ -655,6 +655,32 @@ def test_l2_norm_matches_torch_norm_including_the_lane_broadcast():
         L2_norm(torch.zeros(4, 2), torch.zeros(4, 2))                                               # no CPU path
 
 
+@pytest.mark.parametrize("B,Lq,T,d,H,F,L", [(5, 3, 9, 256, 8, 512, 6), (2, 4, 5, 32, 2, 64, 2), (37, 3, 9, 64, 4, 128, 1)])
+def test_lane_decoder_and_positional_encoding_match_stock_modules(B, Lq, T, d, H, F, L):
+    """nn_component.Lane_Decoder (Transformer_model.py:132-152: decoder pass without a target mask; exported by the reference,
+    instantiated nowhere - no reference fixture exists, so the checker is the same stack of stock torch.nn modules on the CPU:
+    parity unpinned) and PositionalEncoding.forward on its own."""
+    from multimodal_transformer_amd.nn_component import Lane_Decoder, PositionalEncoding
+    dev = _dev()
+    torch.manual_seed(B * 100 + d)
+    mod = Lane_Decoder(32, d, H, F, L, 32)
+    mod.eval()
+    tgt, mem = torch.randn(B, Lq, 32), torch.randn(B, T, d)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[::2, :2] = True
+    with torch.no_grad():
+        x = mod.input_fc(tgt) + mod.pos_encoder.pe[:Lq]
+        want = mod.output_fc(mod.transformer_decoder(x, mem, memory_key_padding_mask=pad))
+        want_nopad = mod.output_fc(mod.transformer_decoder(x, mem))
+    mod.to(dev)
+    got = mod(tgt.to(dev), mem.to(dev), pad.to(dev))
+    assert got.shape == want.shape and rel_err(got.cpu().numpy(), want.numpy()) <= 1e-4
+    assert rel_err(mod(tgt.to(dev), mem.to(dev), None).cpu().numpy(), want_nopad.numpy()) <= 1e-4
+    pe = PositionalEncoding(d).to(dev)
+    y = pe(mem.to(dev))
+    assert torch.equal(y.cpu(), mem + pe.pe[:T].cpu())
+
+
 def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
     """The multi-rank step on one GPU: a one-rank RCCL group, the flat gradient all-reduce issued eagerly between the two HIP-graph
     replays (bench.py --gpus N runs exactly this with N ranks).  A one-rank sum changes nothing: losses and weights equal a run
