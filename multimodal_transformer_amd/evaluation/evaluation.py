@@ -106,3 +106,32 @@ def lane_compute_batch_statistics(prediction_output_dict, dt, max_hl, ph, node_t
     if not best_of:
         raise NotImplementedError("lane statistics are defined as best-of-lanes (evaluation.py:153-156 default)")
     return _statistics(prediction_output_dict, ph, node_type_enum, kde, obs, prune_ph_to_future, device, lanes=True)
+
+
+def _pooled(batch_errors_list):
+    """{(node type label, metric): values of every batch, in order} for the dicts compute_batch_statistics returns."""
+    pooled = {}
+    for errors in batch_errors_list:
+        for node_type, metrics in errors.items():
+            label = getattr(node_type, "name", str(node_type))
+            for metric, values in metrics.items():
+                pooled.setdefault((label, metric), []).extend(values)
+    return {k: v for k, v in pooled.items() if len(v) > 0}
+
+
+def print_batch_errors(batch_errors_list, namespace, curr_iter):
+    """evaluation.py:216-230: mean and median of every metric over all batches, one line each."""
+    for (label, metric), values in _pooled(batch_errors_list).items():
+        print(f"{curr_iter}: {label}/{namespace}/{metric}_mean", np.mean(values))
+        print(f"{curr_iter}: {label}/{namespace}/{metric}_median", np.median(values))
+
+
+def log_batch_errors(batch_errors_list, log_writer, namespace, curr_iter, bar_plot=[], box_plot=[]):
+    """evaluation.py:166-213: histogram + mean + median per metric into a SummaryWriter-like object.  The matplotlib bar / box
+    plots of the reference are visualisation, outside this build (asking for them raises)."""
+    if bar_plot or box_plot:
+        raise NotImplementedError("bar / box plots are visualisation code outside the hot path")
+    for (label, metric), values in _pooled(batch_errors_list).items():
+        log_writer.add_histogram(f"{label}/{namespace}/{metric}", values, curr_iter)
+        log_writer.add_scalar(f"{label}/{namespace}/{metric}_mean", np.mean(values), curr_iter)
+        log_writer.add_scalar(f"{label}/{namespace}/{metric}_median", np.median(values), curr_iter)

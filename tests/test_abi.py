@@ -64,3 +64,36 @@ def test_null_and_empty_arguments_return_einval():
     rc = lib.mmt_decoder_forward(ctypes.byref(dec), None, None, None, None, 0, None, 0, None, 4, 9, 12, None, None,
                                  None, None)
     assert rc == -1
+
+
+def test_batch_error_reporting_helpers(capsys):
+    """evaluation.print_batch_errors / log_batch_errors (evaluation.py:166-230): pooled mean / median over the per-batch dicts
+    that compute_batch_statistics returns; host logic only."""
+    import numpy as np
+    from multimodal_transformer_amd.evaluation import log_batch_errors, print_batch_errors
+
+    class NT:
+        name = "VEHICLE"
+    nt = NT()
+    batches = [{nt: {"ade": [1.0, 3.0], "fde": [2.0], "kde": []}}, {nt: {"ade": [5.0], "fde": [4.0, 9.0], "kde": []}}]
+    print_batch_errors(batches, "eval", 7)
+    out = capsys.readouterr().out.splitlines()
+    assert out == ["7: VEHICLE/eval/ade_mean 3.0", "7: VEHICLE/eval/ade_median 3.0", "7: VEHICLE/eval/fde_mean 5.0",
+                   "7: VEHICLE/eval/fde_median 4.0"]
+
+    class Writer:
+        def __init__(self):
+            self.scalars, self.hists = {}, {}
+
+        def add_scalar(self, tag, value, it):
+            self.scalars[tag] = (float(value), it)
+
+        def add_histogram(self, tag, values, it):
+            self.hists[tag] = (list(values), it)
+    w = Writer()
+    log_batch_errors(batches, w, "eval", 7)
+    assert w.scalars["VEHICLE/eval/ade_mean"] == (3.0, 7) and w.scalars["VEHICLE/eval/fde_median"] == (4.0, 7)
+    assert w.hists["VEHICLE/eval/fde"] == ([2.0, 4.0, 9.0], 7) and "VEHICLE/eval/kde" not in w.hists
+    with pytest.raises(NotImplementedError):
+        log_batch_errors(batches, w, "eval", 7, bar_plot=["kde"])
+    assert np.isclose(w.scalars["VEHICLE/eval/ade_median"][0], 3.0)
