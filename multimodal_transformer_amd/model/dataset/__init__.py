@@ -1,1 +1,2 @@
-from .preprocessing import SceneTable, get_timesteps_data, get_node_timestep_data, present_nodes  # noqa: F401
+from .preprocessing import (SceneTable, collate, get_node_timestep_data, get_timesteps_data, present_nodes,  # noqa: F401
+                            restore)

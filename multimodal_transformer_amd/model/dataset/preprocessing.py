@@ -170,10 +170,57 @@ def get_node_timestep_data(env, scene, t, node, state, pred_state, edge_types, m
     cols = _state_columns(st)
     pred_cols = [cols.index(c) for c in _state_columns(pred_state[node.type])]
     fhi, x, y, x_st, y_st = gather(table, np.array([idx]), np.array([int(t)]), max_ht, max_ft, pred_cols)
-    lane_tuple = None
-    if hyperparams.get("lane_cnn_encoding"):
+    lane_tuple = map_tuple = None
+    if hyperparams.get("map_cnn_encoding") or hyperparams.get("map_vit_encoding"):
+        # (scene map, current position, heading, patch size): cropped per batch by collate (preprocessing.py:147-169, :32-40)
+        me = hyperparams["map_encoder"]["cnn_param"]
+        cur = table.flat_h[table.row_off_h[idx] + (int(t) - table.first_h[idx])]
+        heading = None
+        if "heading_state_index" in me:
+            hsi = me["heading_state_index"]
+            heading = float(-np.arctan2(cur[hsi[1]], cur[hsi[0]]) * 180 / np.pi if isinstance(hsi, (list, tuple))
+                            else -cur[hsi] * 180 / np.pi)
+        map_tuple = (scene.map[node.type], cur[:2].copy(), heading, me["patch_size"])
+    elif hyperparams.get("lane_cnn_encoding"):
         lane_tuple = tuple(v[0] for v in gather_lanes(table, np.array([idx]), np.array([int(t)]), max_ft))
-    return fhi[0], x[0], y[0], x_st[0], y_st[0], None, None, None, lane_tuple, None
+    return fhi[0], x[0], y[0], x_st[0], y_st[0], None, None, None, lane_tuple, map_tuple
+
+
+def restore(data):
+    """preprocessing.py:9-19: structures that a DataLoader worker serialised with dill come back; anything else passes through."""
+    if isinstance(data, bytes):
+        import dill
+        return dill.loads(data)
+    return data
+
+
+def collate(batch):
+    """``collate_fn`` for per-node elements of get_node_timestep_data (preprocessing.py:22-55): tensors are stacked; a 4-tuple
+    element is (scene map, point, heading, patch size) and becomes the batch of cropped map patches (one ``mmt_map_crop`` launch); a
+    3-tuple element is the lane tuple and becomes three per-node tuples; other sequences are collated field by field; dict
+    elements become a dict of lists (dill-serialised inside a DataLoader worker, see ``restore``)."""
+    import collections.abc as abc
+    if len(batch) == 0:
+        return batch
+    first = batch[0]
+    if first is None:
+        return None
+    if isinstance(first, abc.Sequence) and not isinstance(first, (str, bytes)):
+        if len(first) == 4:
+            maps, points, headings, patch = zip(*batch)
+            rotation = None if headings[0] is None else torch.tensor(headings)
+            return maps[0].get_cropped_maps_from_scene_map_batch(maps, scene_pts=torch.tensor(np.array(points)),
+                                                                 patch_size=patch[0], rotation=rotation)
+        if len(first) == 3:
+            return [field for field in zip(*batch)]
+        return [collate(field) for field in zip(*batch)]
+    if isinstance(first, abc.Mapping):
+        merged = {key: [item[key] for item in batch] for key in first}
+        if torch.utils.data.get_worker_info():
+            import dill
+            return dill.dumps(merged)
+        return merged
+    return torch.utils.data.default_collate(batch)
 
 
 def _map_patches(scene, node_type, n, cur, hyperparams, device):

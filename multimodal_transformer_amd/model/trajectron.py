@@ -49,7 +49,13 @@ class Trajectron(object):
         lane_input = None
         if self.hyperparams["lane_cnn_encoding"]:
             # reference batches: a tuple of (Ln,P,2) arrays (trajectron.py:62-63); the vectorised builder: one device tensor
-            lane_input = lanes[0] if torch.is_tensor(lanes[0]) else torch.as_tensor(np.array(lanes[0]), dtype=torch.float32)
+            # ... or, from collate, a tuple of per-node device tensors
+            if torch.is_tensor(lanes[0]):
+                lane_input = lanes[0]
+            elif len(lanes[0]) and torch.is_tensor(lanes[0][0]):
+                lane_input = torch.stack(list(lanes[0]))
+            else:
+                lane_input = torch.as_tensor(np.array(lanes[0]), dtype=torch.float32)
             lane_input = lane_input.to(self.device)
         dev = lambda t: t.to(self.device) if isinstance(t, torch.Tensor) else None
         return dev(x_t), dev(y_t), dev(x_st_t), dev(y_st_t), lane_input, dev(map)

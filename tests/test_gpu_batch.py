@@ -211,3 +211,41 @@ def test_batch_statistics_equal_reference_outputs():
     got = tr.evaluate(scene, ts, 12, min_history_timesteps=1)["VEHICLE"]
     assert len(got["ade"]) == len(want["ade"]) > 0
     assert np.max(np.abs(got["ade"] - np.array(want["ade"]))) <= 1e-3 and np.max(np.abs(got["fde"] - np.array(want["fde"]))) <= 1e-3
+
+
+def test_collate_of_per_node_elements_equals_the_vectorised_batch():
+    """preprocessing.collate / restore (preprocessing.py:9-55) over get_node_timestep_data elements == get_timesteps_data for the
+    same (node, timestep) pairs: state tensors, lane tuples, and the cropped map patches (4-tuple branch -> one mmt_map_crop launch)."""
+    from multimodal_transformer_amd.environment import GeometricMap
+    from multimodal_transformer_amd.model.dataset import collate, get_node_timestep_data, get_timesteps_data, restore
+    z = np.load(os.path.join(GOLD, "batch.npz"))
+    zl = np.load(os.path.join(GOLD, "batch_lane.npz"))
+    zm = np.load(os.path.join(GOLD, "mapcrop.npz"))
+    scene = _scene(_split(z["table"], z["lengths"]), z["first"], _split(zl["lanes"], z["lengths"]))
+    scene.map = {"VEHICLE": GeometricMap(zm["raster0"], zm["homography0"])}
+    ts = np.array([20, 21])
+    map_hp = {"map_encoder": {"cnn_param": {"heading_state_index": 6, "patch_size": [50, 10, 50, 90]}}}
+    for extra in ({}, {"lane_cnn_encoding": True}, dict(map_hp, map_cnn_encoding=True)):
+        hp = dict(HP, **extra)
+        batch, nodes, out_ts = get_timesteps_data(env=None, scene=scene, t=ts, node_type="VEHICLE", state=STATE, pred_state=PRED,
+                                                  edge_types=None, min_ht=1, max_ht=8, min_ft=12, max_ft=12, hyperparams=hp)
+        items = [get_node_timestep_data(None, scene, t, n, STATE, PRED, None, 8, 12, hp) for n, t in zip(nodes, out_ts)]
+        got = collate(items)
+        assert len(got) == 10 and all(g is None for g in got[5:8])
+        for a, b in zip(got[:5], batch[:5]):
+            assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        if hp["lane_cnn_encoding"]:
+            pts, label, mask = got[8]
+            assert len(pts) == len(nodes) and torch.equal(torch.stack(list(pts)), batch[8][0])
+            assert torch.equal(torch.stack(list(label)), batch[8][1]) and torch.equal(torch.stack(list(mask)), batch[8][2])
+        else:
+            assert got[8] is None
+        if hp["map_cnn_encoding"]:
+            assert got[9].shape == (len(nodes), 3, 100, 100) and torch.equal(got[9], batch[9])
+        else:
+            assert got[9] is None
+    assert collate([]) == [] and collate([None, None]) is None
+    d = collate([{"a": 1, "b": 2}, {"a": 3, "b": 4}])
+    assert d == {"a": [1, 3], "b": [2, 4]} and restore(d) is d
+    import dill
+    assert restore(dill.dumps(d)) == d
