@@ -327,6 +327,38 @@ def test_train_and_test_decoder_wrappers_match_oracle(tiny):
     assert torch.equal(h_tf, mb.non_at_dec(memory, None, pad, yb_st, n0, None, None, ph)[0])
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_trajectron_batch_entry_points_match_reference_golden(mode):
+    """Trajectron.{train_loss, eval_loss, predict_batch} on the reference's 10-tuple batch (trajectron.py:58-135): the tuple is
+    unpacked, moved to the device and handed to the node model; lane batches arrive as a tuple of per-node (3,10,2) arrays
+    (trajectron.py:62-65).  Values against the goldens of the real reference."""
+    import types
+    from multimodal_transformer_amd.model import ModelRegistrar
+    from multimodal_transformer_amd.model.trajectron import Trajectron
+    dev = _dev()
+    z, _ = load_golden("tiny_" + mode)
+    hp, B, ph = hp_for(mode, True)
+    reg = ModelRegistrar("/tmp", dev)
+    tr = Trajectron(reg, hp, None, dev)
+    tr.set_environment(types.SimpleNamespace(NodeType=["VEHICLE"], get_edge_types=lambda: [], robot_type=None))
+    set_weights(reg.model_dict, True, z)
+    b = batch_for(mode, True)
+    t = {k: torch.from_numpy(v) for k, v in b.items()}          # host tensors, like a DataLoader batch
+    lanes = None
+    if mode == "lane_cnn":
+        lanes = [tuple(b["lanes"][i] for i in range(B)), None, None]
+    batch = (torch.zeros(B, dtype=torch.long), t["x"], t["y"], t["x_st"], t["y_st"], None, None, None, lanes, t.get("map"))
+    loss, reg_loss = tr.train_loss(batch, "VEHICLE")
+    assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"])) and float(reg_loss) == float(loss)
+    ev, ev_reg = tr.eval_loss(batch, "VEHICLE")
+    assert isinstance(ev, np.ndarray) and abs(float(ev) - float(z["eval_loss"])) <= TOL * abs(float(z["eval_loss"]))
+    hist, lane = tr.predict_batch(batch, "VEHICLE", ph)
+    pred = (lane if mode == "lane_cnn" else hist).cpu().numpy()
+    node = b["x"][:, -1, 0:2]
+    node = node[:, None, None, :] if mode == "lane_cnn" else node[:, None, :]
+    assert rel_err((pred - node) / 80.0, (z["predict"] - node) / 80.0) <= TOL
+
+
 def test_large_batch_properties():
     """BASELINE config 5 size on one GPU (8192/8 = 1024 agents): finite, and rows equal the B=128 run."""
     dev = _dev()
