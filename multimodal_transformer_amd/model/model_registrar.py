@@ -29,7 +29,7 @@ def install_reference_aliases():
     pkg.__path__ = []
     pkg.__mmt_alias__ = True
     layout = {
-        "Transformer_model": ["Encoder", "Decoder", "Trajectory_Decoder", "PositionalEncoding"],
+        "Transformer_model": ["Encoder", "Decoder", "Lane_Decoder", "Trajectory_Decoder", "PositionalEncoding"],
         "MLP": ["Mlp"], "map_encoder": ["CNNMapEncoder"], "Lane_encoder": ["Lane_Encoder"],
     }
     for sub, names in layout.items():

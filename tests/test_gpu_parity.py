@@ -359,6 +359,32 @@ def test_trajectron_batch_entry_points_match_reference_golden(mode):
     assert rel_err((pred - node) / 80.0, (z["predict"] - node) / 80.0) <= TOL
 
 
+def test_checkpoint_round_trip_after_the_kernels_have_run(tmp_path):
+    """ModelRegistrar.save_models / load_models (model_registrar.py:58-75): ``model_registrar-<iter>.pt`` = the pickled ModuleDict.
+    Saved AFTER a predict (packed device descriptors exist and must not be pickled), loaded into a fresh registrar: same keys, same
+    tensors, same prediction bit for bit."""
+    from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+    dev = _dev()
+    hp, B, ph = hp_for("map_cnn", True)
+    z, _ = load_golden("tiny_map_cnn")
+    model, reg = _model(hp, dev)
+    reg.model_dir = str(tmp_path)
+    set_weights(reg.model_dict, True, z)
+    x, x_st, y, y_st, lanes, maps = _to(batch_for("map_cnn", True), dev)
+    before = model.predict(x, x_st, lanes, None, maps, ph)[0]
+    reg.save_models(7)
+    assert (tmp_path / "model_registrar-7.pt").exists()
+    reg2 = ModelRegistrar(str(tmp_path), dev)
+    reg2.load_models(7)
+    assert list(reg2.model_dict.keys()) == list(reg.model_dict.keys())
+    for (ka, a), (kb, b) in zip(reg.model_dict.state_dict().items(), reg2.model_dict.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+    model2 = MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg2, hp, dev, [])
+    assert torch.equal(model2.predict(x, x_st, lanes, None, maps, ph)[0], before)
+    with pytest.raises(ValueError):
+        reg2.get_model("VEHICLE/never_registered")
+
+
 def test_large_batch_properties():
     """BASELINE config 5 size on one GPU (8192/8 = 1024 agents): finite, and rows equal the B=128 run."""
     dev = _dev()
