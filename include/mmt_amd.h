@@ -245,6 +245,13 @@ size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph
 #define MMT_DECODER_CLUSTER 2
 #define MMT_DECODER_CLUSTER_LAUNCHES 3
 int mmt_decoder_select(int impl);
+/* Synchronises `stream` and reports whether a one-launch decode issued on the current device gave up on a wait since the
+ * last call: MMT_OK, or MMT_ELAUNCH (that decode's outputs are NaN; the fault is cleared and the one-launch form stays
+ * disabled on this device, so re-issuing the call runs launch-per-phase).  Callers check it where they synchronise anyway
+ * (the reference copies every prediction to the host, trajectron.py:216-221).  No counterpart in the reference. */
+int mmt_decoder_status(void *stream);
+/* test hook: the next one-launch decodes lose one workgroup (their waits must time out); 0 re-arms.  Not for production. */
+int mmt_debug_decoder_stall(int on);
 int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
                         const float *start_pos, const float *map_feat, int map_dim,
                         const float *mem_feat, int mem_feat_dim, const float *tgt, int B, int T, int ph,

@@ -125,6 +125,8 @@ SIGNATURES = {
     "mmt_decoder_select": (C.c_int, [C.c_int]),
     "mmt_decoder_forward": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
                                       C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
+    "mmt_decoder_status": (C.c_int, [C.c_void_p]),
+    "mmt_debug_decoder_stall": (C.c_int, [C.c_int]),
     "mmt_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mmt_pack_conv": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_cnn_workspace_floats": (C.c_size_t, [C.POINTER(Cnn), C.c_int]),

@@ -22,13 +22,19 @@
 #include "mmt_gfx950.cuh"
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
+#include <mutex>
 #include <type_traits>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
 int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
+
+// Sticky per-device fault word: raised by the final head launch of a decode whose in-kernel hand-offs timed out (the outputs of
+// that call are NaN).  Read and cleared by mmt_decoder_status().
+__device__ unsigned g_decoder_fault;
 
 #ifdef MMT_PROFILE
 // diagnostic build: wall-clock (100 MHz) stamps per launch / workgroup / stage, read by tools/cluster_profile.py
@@ -520,6 +526,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
       // the fused kernel gave up on a wait (a workgroup of a cluster was not resident): fail loudly, never return stale numbers
       if (a.tmo && __hip_atomic_load((const gu32 *)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         __syncthreads();
+        if (tid == 0 && cluster == 0) atomicOr(&g_decoder_fault, 1u);      // sticky: mmt_decoder_status() reports and clears it
         if (a.pred_st)
           for (int i = tid; i < na * a.ph * a.n_in; i += CNT) a.pred_st[(size_t)a0 * a.ph * a.n_in + i] = __builtin_nanf("");
         if (a.h_out)
@@ -1191,16 +1198,52 @@ int mlp_width(const mmt_mlp &m) {
   return w;
 }
 
+// Environment knobs, read ONCE (first use): MMT_CLUSTER_ROWS=4|8|16, MMT_NO_MFMA4, MMT_NO_FUSED_DECODER.
+struct DecEnv {
+  int cluster_rows;
+  bool no_mfma4, no_fused;
+  DecEnv() : cluster_rows(0), no_mfma4(getenv("MMT_NO_MFMA4") != nullptr), no_fused(getenv("MMT_NO_FUSED_DECODER") != nullptr) {
+    if (const char *e = getenv("MMT_CLUSTER_ROWS")) {
+      const int v = atoi(e);
+      if (v == 4 || v == 8 || v == 16) cluster_rows = v;
+    }
+  }
+};
+const DecEnv &dec_env() {
+  static const DecEnv e;       // thread-safe initialisation (C++11)
+  return e;
+}
+
+// Per-device host state (the library may be driven from several devices / threads of one process).
+constexpr int MAX_DEV = 64;
+struct DevState {
+  std::atomic<int> ncu{0};
+  std::atomic<bool> fused_disabled{false};     // set by mmt_decoder_status() after a timed-out one-launch decode
+  std::atomic<unsigned> attr_mask{0};          // kernel families whose LDS attribute has been raised on this device
+};
+DevState g_dev[MAX_DEV];
+std::atomic<int> g_test_stall{0};              // fault injection (tests): mmt_debug_decoder_stall()
+
+int cur_dev() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev < 0 || dev >= MAX_DEV ? 0 : dev;
+}
+int dev_ncu(int dev) {
+  int n = g_dev[dev].ncu.load(std::memory_order_relaxed);
+  if (n <= 0) {
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    g_dev[dev].ncu.store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 // Agents per cluster: 16 fills the MFMA tile; small batches use fewer so that more CUs share the work (every
 // workgroup takes in its weight slice at ~50 GB/s, and the partials it sums scale with the rows).
 int cluster_rows(int B, int H) {
-  if (const char *e = getenv("MMT_CLUSTER_ROWS")) {
-    const int v = atoi(e);
-    if (v == 4 || v == 8 || v == 16) return v;
-  }
-  int dev = 0, ncu = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (dec_env().cluster_rows) return dec_env().cluster_rows;
+  const int ncu = dev_ncu(cur_dev());
   int rc = 16;
   while (rc > 4 && ((B + rc / 2 - 1) / (rc / 2)) * H <= ncu) rc /= 2;
   return rc;
@@ -1212,7 +1255,7 @@ bool lin4_second_ok(int n, int slice_k) { return n % 4 == 0 && slice_k % 4 == 0 
 
 // 4-agent clusters on the 4x4x1 path: packed copies present and every linear within the kernels' register budget.
 bool mfma4_fits(const mmt_decoder *dec) {
-  if (getenv("MMT_NO_MFMA4")) return false;
+  if (dec_env().no_mfma4) return false;
   const int d = dec->d_model, H = dec->nhead, DH = d / H, FS = dec->d_ff / H;
   for (int l = 0; l < dec->nlayers; ++l) {
     const mmt_dec_layer &W = dec->layer[l];
@@ -1352,8 +1395,10 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
   const size_t lds_c = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256) * sizeof(float);
   const size_t lds_a = lds_c + (size_t)16 * KMAX * (DH + 4) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  // hipFuncSetAttribute is per device: raise the dynamic-LDS limit once per (device, kernel family)
+  const unsigned fam_bit = 1u << ((DH == 32 ? 0 : 1) + 2 * (CPW - 1) + 4 * (M4 ? 1 : 0));
+  DevState &ds = g_dev[cur_dev()];
+  if (!(ds.attr_mask.load(std::memory_order_acquire) & fam_bit)) {
 #define SET_LDS(PHASE, XM, BYTES)                                                                                                     \
   do {                                                                                                                                \
     (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
@@ -1370,7 +1415,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 #undef SET_LDS
     if constexpr (M4)
       (void)hipFuncSetAttribute((const void *)mmt_dec_fused4_kernel<DH, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-    attr_done = true;
+    ds.attr_mask.fetch_or(fam_bit, std::memory_order_release);
   }
 #define LAUNCH_PHASE(PHASE, XM, BYTES)                                                                     \
   do {                                                                                                     \
@@ -1406,7 +1451,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       f.memkv = memkv;
       f.sync = sync;
       f.nlayers = L;
-      f.test_stall = getenv("MMT_TEST_FUSED_STALL") ? 1 : 0;
+      f.test_stall = g_test_stall.load(std::memory_order_relaxed);
       hipLaunchKernelGGL((mmt_dec_fused4_kernel<DH, CPW>), grid, blk, lds_a, st, f);
       p = 3 * L * ph;
       a.tmo = sync;
@@ -1455,6 +1500,43 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   return MMT_OK;
 }
 
+// The one-launch kernel spins on its siblings: it is only started when the occupancy query says the whole grid is resident.
+static bool fused_grid_fits(bool cpw2, int grid, int ncu, int d) {
+  constexpr int DH = 32;
+  constexpr int LD1 = 3 * DH + 8;
+  const size_t lds = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256 +
+                      (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
+  int per_cu = 0;
+  const hipError_t e = cpw2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 2>, CNT, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 1>, CNT, lds);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return per_cu >= 1 && grid <= per_cu * ncu;
+}
+
+// Reports (and clears) a timed-out one-launch decode on the current device; see include/mmt_amd.h.
+extern "C" int mmt_decoder_status(void *stream) {
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_status: %s", hipGetErrorString(e));
+  unsigned v = 0;
+  e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_decoder_fault), sizeof(v));
+  if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_status: %s", hipGetErrorString(e));
+  if (!v) return MMT_OK;
+  const unsigned zero = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_decoder_fault), &zero, sizeof(zero));
+  g_dev[cur_dev()].fused_disabled.store(true, std::memory_order_relaxed);
+  return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_forward: a one-launch decode on this device gave up waiting for a workgroup of "
+                                    "its cluster (GPU shared or CU-masked?); that call's outputs are NaN.  The one-launch form is "
+                                    "now disabled on this device: re-issue the call (it runs launch-per-phase)");
+}
+extern "C" int mmt_debug_decoder_stall(int on) {
+  g_test_stall.store(on ? 1 : 0, std::memory_order_relaxed);
+  if (!on) g_dev[cur_dev()].fused_disabled.store(false, std::memory_order_relaxed);   // tests re-arm the one-launch form
+  return MMT_OK;
+}
+
 // Same contract as mmt_decoder_forward (arguments already validated there).
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
@@ -1476,11 +1558,13 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   unsigned *sync = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(after) + 127) & ~(uintptr_t)127);
   // One launch for all phases when every workgroup of the decode is resident at once (one per CU: the phase kernels need
   // > 80 KB of LDS) and the 4x4x1 path applies; else a launch per phase.  MMT_NO_FUSED_DECODER=1 forces the latter.
-  int dev = 0, ncu = 0;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int dev = cur_dev(), ncu = dev_ncu(dev);
   const bool m4 = RC == 4 && mfma4_fits(dec);
-  const bool fuse_phases = allow_fused && m4 && NC * H <= ncu && !getenv("MMT_NO_FUSED_DECODER");
+  // All NC*H workgroups must be resident at once: one per CU by their LDS footprint, checked against the occupancy query
+  // (not the CU count alone).  A device whose one-launch decode has timed out before (mmt_decoder_status) is not trusted again.
+  bool fuse_phases = allow_fused && m4 && NC * H <= ncu && !dec_env().no_fused &&
+                     !g_dev[dev].fused_disabled.load(std::memory_order_relaxed);
+  if (fuse_phases) fuse_phases = fused_grid_fits(d > 128, NC * H, ncu, d);
 
   const float *src = memory;
   const int rows = B * T;

@@ -387,9 +387,11 @@ __global__ __launch_bounds__(1024) void mmt_finalize_kernel(const float *__restr
 
 // ================================================================================ host side
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 int mmt_set_error(int code, const char *fmt, ...) {   // shared with context.hip (not part of the C ABI)
@@ -491,11 +493,11 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
                                 bool allow_fused, void *stream);
 
-static int g_decoder_impl = MMT_DECODER_AUTO;
+static std::atomic<int> g_decoder_impl_atomic{MMT_DECODER_AUTO};     // process-wide tuning knob; each call reads it once
 extern "C" int mmt_decoder_select(int impl) {
   if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_LAUNCHES)
     return fail(MMT_EINVAL, "mmt_decoder_select: unknown implementation %d", impl);
-  g_decoder_impl = impl;
+  g_decoder_impl_atomic.store(impl, std::memory_order_relaxed);
   return MMT_OK;
 }
 
@@ -509,6 +511,7 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
                                    int mem_feat_dim, const float *tgt, int B, int T, int ph, float *pred_st,
                                    float *h_out, float *workspace, void *stream) {
   if (!dec || !memory || !workspace) return fail(MMT_EINVAL, "mmt_decoder_forward: null pointer");
+  const int g_decoder_impl = g_decoder_impl_atomic.load(std::memory_order_relaxed);
   if (B <= 0) return fail(MMT_EINVAL, "mmt_decoder_forward: empty batch (B=%d)", B);
   if (T <= 0 || T > 32) return fail(MMT_EINVAL, "mmt_decoder_forward: memory length T=%d outside 1..32", T);
   if (ph <= 0 || ph > 32) return fail(MMT_EINVAL, "mmt_decoder_forward: horizon ph=%d outside 1..32", ph);

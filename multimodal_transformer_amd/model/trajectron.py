@@ -8,6 +8,7 @@ reference's signature, or use ``predict_batch`` on an already collated batch.
 import numpy as np
 import torch
 
+from .. import ops
 from .mgcvae import MultimodalGenerativeCVAE
 
 
@@ -68,9 +69,9 @@ class Trajectron(object):
 
     def eval_loss(self, batch, node_type):
         x, y, x_st, y_st, lanes, map = self._unpack(batch)
-        loss, reg = self.node_models_dict[node_type].eval_loss(
+        loss, reg = ops.checked(lambda: self.node_models_dict[node_type].eval_loss(
             node_type, inputs=x, inputs_st=x_st, inputs_lane=lanes, lane_label=None, lane_t_mask=None, labels=y,
-            labels_st=y_st, map=map, prediction_horizon=self.ph)
+            labels_st=y_st, map=map, prediction_horizon=self.ph))
         return loss.cpu().detach().numpy(), reg.cpu().detach().numpy()
 
     def predict_batch(self, batch, node_type, ph):
@@ -96,7 +97,8 @@ class Trajectron(object):
             if batch is None:
                 continue
             tensors, nodes, timesteps_o = batch
-            hist, lane = self.predict_batch(tensors, node_type, ph)
+            # (the results are copied to the host below: the place to learn that a one-launch decode gave up, and to re-issue it)
+            hist, lane = ops.checked(lambda: self.predict_batch(tensors, node_type, ph))
             if self.hyperparams["lane_cnn_encoding"]:
                 arr = lane.cpu().numpy()                       # (B, L, ph, 2): one device->host copy
                 for i, ts in enumerate(timesteps_o):
@@ -129,7 +131,7 @@ class Trajectron(object):
             if batch is None:
                 continue
             tensors, nodes, timesteps_o = batch
-            hist, lane = self.predict_batch(tensors, node_type, ph)
+            hist, lane = ops.checked(lambda: self.predict_batch(tensors, node_type, ph))
             y = tensors[2].to(self.device)
             pred = lane if self.hyperparams["lane_cnn_encoding"] else hist
             # relative to the current position (column 0:2 of the last history row): keeps the fp32 reduction exact to ~1e-6 m

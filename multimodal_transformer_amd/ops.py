@@ -494,6 +494,26 @@ def decoder_select(impl: str = "auto"):
     _lib.check(_lib.load().mmt_decoder_select(table[impl]), "mmt_decoder_select")
 
 
+def decoder_status(stream=None):
+    """Synchronise and raise MmtError if a one-launch decode on the current device timed out since the last check (its outputs
+    are NaN; the library then keeps that form disabled on the device, so re-issuing the call succeeds)."""
+    _lib.check(_lib.load().mmt_decoder_status(_stream() if stream is None else stream), "mmt_decoder_status")
+
+
+def checked(fn):
+    """Run ``fn`` (a callable that launches decodes and returns device tensors), then check the decoder status at the caller's
+    synchronisation point; on a timed-out one-launch decode re-issue ``fn`` once (it then runs launch-per-phase)."""
+    out = fn()
+    try:
+        decoder_status()
+    except MmtError as e:
+        import warnings
+        warnings.warn(f"{e}; re-issuing", RuntimeWarning)
+        out = fn()
+        decoder_status()
+    return out
+
+
 _ws_cache = {}
 
 

@@ -230,30 +230,49 @@ def test_fused_decoder_is_bit_identical_to_launch_per_phase():
             torch.cuda.synchronize()
 
 
-def test_fused_decoder_times_out_loudly(monkeypatch):
-    """Fault injection: one workgroup of cluster 0 leaves the fused kernel early (MMT_TEST_FUSED_STALL), so its siblings can
-    never complete their wait.  Every wait is bounded: the launch ends (0.2 s), the time-out word makes the final head launch
-    return NaN for the WHOLE call (never stale numbers), and the next call is clean again."""
+def test_fused_decoder_times_out_loudly():
+    """Fault injection: one workgroup of cluster 0 leaves the one-launch decoder early (mmt_debug_decoder_stall), so its siblings
+    can never complete their wait.  Every wait is bounded: the launch ends (0.2 s), the final head launch turns the WHOLE call's
+    outputs into NaN (never stale numbers) and raises the device's fault word; mmt_decoder_status reports it as MMT_ELAUNCH, clears
+    it and keeps the one-launch form off on this device, so the re-issued call (ops.checked does that) returns the right numbers."""
     import time
-    from multimodal_transformer_amd import ops
+    from multimodal_transformer_amd import _lib, ops
+    from multimodal_transformer_amd._lib import MmtError
     dev = _dev()
+    lib = _lib.load()
     hp = make_hyperparams("basic", history=8, horizon=12)
     model, reg = _model(hp, dev)
     apply_recipe(reg.model_dict, seed=0)
     x, x_st, *_ = _to(make_batch(64, 8, 12, seed=2), dev)
     ops.decoder_select("cluster")
     want, _ = model.predict(x, x_st, None, None, None, 12)
-    torch.cuda.synchronize()
-    monkeypatch.setenv("MMT_TEST_FUSED_STALL", "1")
-    t0 = time.perf_counter()
-    bad, _ = model.predict(x, x_st, None, None, None, 12)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert torch.isnan(bad).all()
-    assert 0.1 < dt < 5.0
-    monkeypatch.delenv("MMT_TEST_FUSED_STALL")
-    again, _ = model.predict(x, x_st, None, None, None, 12)
-    assert torch.equal(want, again)
+    ops.decoder_status()                                  # clean so far
+    try:
+        lib.mmt_debug_decoder_stall(1)
+        t0 = time.perf_counter()
+        bad, _ = model.predict(x, x_st, None, None, None, 12)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isnan(bad).all()
+        assert 0.1 < dt < 5.0
+        with pytest.raises(MmtError, match="gave up"):
+            ops.decoder_status()
+        ops.decoder_status()                              # reported once, then clear
+        # the one-launch form is now off on this device: the same call (stall still armed) runs launch-per-phase and is right
+        again, _ = model.predict(x, x_st, None, None, None, 12)
+        assert torch.equal(want, again)
+        ops.decoder_status()
+        # and the wrapper the callers use re-issues by itself
+        lib.mmt_debug_decoder_stall(0)                    # re-arms the one-launch form
+        lib.mmt_debug_decoder_stall(1)
+        with pytest.warns(RuntimeWarning, match="re-issuing"):
+            healed, _ = ops.checked(lambda: model.predict(x, x_st, None, None, None, 12))
+        assert torch.equal(want, healed)
+    finally:
+        lib.mmt_debug_decoder_stall(0)
+    fresh, _ = model.predict(x, x_st, None, None, None, 12)
+    assert torch.equal(want, fresh)
+    ops.decoder_status()
 
 
 def test_teacher_forced_decoder_full_width_agrees_across_kernel_families():
