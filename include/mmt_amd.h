@@ -257,6 +257,18 @@ int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8
                         const float *mem_feat, int mem_feat_dim, const float *tgt, int B, int T, int ph,
                         float *pred_st, float *h_out, float *workspace, void *stream);
 
+/* The same decode for callers that cannot allocate device memory or bring a workspace (code under HIP-graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  The workspace is a file-scope device
+ * array of MMT_DECODER_STATIC_SCRATCH_FLOATS floats (44 MiB per GPU the library runs on, held until the process ends); sizes
+ * whose mmt_decoder_workspace_floats() exceeds it are rejected with MMT_EINVAL.  Calls no hipMalloc / hipFree.  Every call on
+ * a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race - serialise them.  Results are
+ * bit-identical to mmt_decoder_forward. */
+#define MMT_DECODER_STATIC_SCRATCH_FLOATS (11u << 20)
+int mmt_decoder_forward_static(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
+                               const float *start_pos, const float *map_feat, int map_dim,
+                               const float *mem_feat, int mem_feat_dim, const float *tgt, int B, int T, int ph,
+                               float *pred_st, float *h_out, void *stream);
+
 /* conv weight [Co][Ci][ks][ks] -> packed[tap][ci/4][co/16][lane = 16*(ci%4) + co%16], zero padded (new, no counterpart) */
 size_t mmt_packed_conv_floats(int Co, int Ci, int ks);
 int mmt_pack_conv(const float *w, int Co, int Ci, int ks, float *dst, void *stream);

@@ -12,6 +12,7 @@ import os
 MMT_MAX_LAYERS = 8
 MMT_MAX_MLP_HIDDEN = 3
 MMT_MAX_CONV = 4
+MMT_DECODER_STATIC_SCRATCH_FLOATS = 11 << 20
 MMT_DECODER_AUTO, MMT_DECODER_PERSISTENT, MMT_DECODER_CLUSTER, MMT_DECODER_CLUSTER_LAUNCHES = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -125,6 +126,8 @@ SIGNATURES = {
     "mmt_decoder_select": (C.c_int, [C.c_int]),
     "mmt_decoder_forward": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
                                       C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
+    "mmt_decoder_forward_static": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
+                                             C.c_int, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_decoder_status": (C.c_int, [C.c_void_p]),
     "mmt_debug_decoder_stall": (C.c_int, [C.c_int]),
     "mmt_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

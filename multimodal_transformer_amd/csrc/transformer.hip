@@ -589,6 +589,49 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   return check_launch("mmt_decoder_forward");
 }
 
+// ---- the same decode for callers that cannot allocate (include/mmt_amd.h: mmt_decoder_forward_static) ----------------------
+// The workspace is a file-scope device array.  Its NAME is only a host-side stand-in for the symbol: the device address is
+// looked up once per device with hipGetSymbolAddress (each GPU holds its own copy at its own address) and only that pointer is
+// ever handed to kernels.
+static __device__ __align__(256) float scratch[MMT_DECODER_STATIC_SCRATCH_FLOATS];
+static float *g_scratch_ptr[64];
+static std::mutex g_scratch_mu;
+
+static int static_scratch(float **out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(MMT_ELAUNCH, "mmt_decoder_forward_static: hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= 64) return fail(MMT_EINVAL, "mmt_decoder_forward_static: device index %d outside 0..63", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    float *p = nullptr;
+    e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));     // with device `dev` current: that device's copy
+    if (e != hipSuccess || !p)
+      return fail(MMT_ELAUNCH, "mmt_decoder_forward_static: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return MMT_OK;
+}
+
+extern "C" int mmt_decoder_forward_static(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
+                                          const float *start_pos, const float *map_feat, int map_dim, const float *mem_feat,
+                                          int mem_feat_dim, const float *tgt, int B, int T, int ph, float *pred_st, float *h_out,
+                                          void *stream) {
+  if (!dec) return fail(MMT_EINVAL, "mmt_decoder_forward_static: null pointer");
+  if (B <= 0 || T <= 0 || ph <= 0) return fail(MMT_EINVAL, "mmt_decoder_forward_static: bad sizes B=%d T=%d ph=%d", B, T, ph);
+  const size_t need = mmt_decoder_workspace_floats(dec, B, T, ph);
+  if (need == 0 || need > (size_t)MMT_DECODER_STATIC_SCRATCH_FLOATS)
+    return fail(MMT_EINVAL, "mmt_decoder_forward_static: B=%d T=%d ph=%d needs %zu floats of scratch, the static buffer holds %zu "
+                            "(use mmt_decoder_forward with a caller workspace)", B, T, ph, need, (size_t)MMT_DECODER_STATIC_SCRATCH_FLOATS);
+  float *ws = nullptr;
+  if (int rc = static_scratch(&ws)) return rc;
+  // nothing in the scratch has to start at zero: every decode zeroes its own hand-off counters (cross-K/V kernel) and writes
+  // each partial / cache row before it reads it
+  return mmt_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T, ph, pred_st,
+                             h_out, ws, stream);
+}
+
 extern "C" int mmt_finalize(const float *pred_st, const float *node_pos, const float *gt, int metric_in_metres, int B,
                             int ph, float *pred_m, float *ade, float *fde, float *loss_sum, void *stream) {
   if (!pred_st || B <= 0 || ph <= 0) return fail(MMT_EINVAL, "mmt_finalize: bad arguments");
