@@ -244,6 +244,8 @@ size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph
 #define MMT_DECODER_PERSISTENT 1
 #define MMT_DECODER_CLUSTER 2
 #define MMT_DECODER_CLUSTER_LAUNCHES 3
+#define MMT_DECODER_CLUSTER_FUSED 4      /* CLUSTER, one-launch forms: only the fused kernel (every workgroup runs every phase)    */
+#define MMT_DECODER_CLUSTER_PIPELINE 5   /* CLUSTER, one-launch forms: only the weight-stationary pipeline (a workgroup = a stage) */
 int mmt_decoder_select(int impl);
 /* Synchronises `stream` and reports whether a one-launch decode issued on the current device gave up on a wait since the
  * last call: MMT_OK, or MMT_ELAUNCH (that decode's outputs are NaN; the fault is cleared and the one-launch form stays

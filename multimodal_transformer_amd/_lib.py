@@ -14,6 +14,7 @@ MMT_MAX_MLP_HIDDEN = 3
 MMT_MAX_CONV = 4
 MMT_DECODER_STATIC_SCRATCH_FLOATS = 11 << 20
 MMT_DECODER_AUTO, MMT_DECODER_PERSISTENT, MMT_DECODER_CLUSTER, MMT_DECODER_CLUSTER_LAUNCHES = 0, 1, 2, 3
+MMT_DECODER_CLUSTER_FUSED, MMT_DECODER_CLUSTER_PIPELINE = 4, 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMT_AMD_LIB", os.path.join(_HERE, "libmmt_amd.so"))   # override: diagnostic builds only

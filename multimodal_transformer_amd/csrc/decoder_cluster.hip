@@ -35,6 +35,7 @@ int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
 // Sticky per-device fault word: raised by the final head launch of a decode whose in-kernel hand-offs timed out (the outputs of
 // that call are NaN).  Read and cleared by mmt_decoder_status().
 __device__ unsigned g_decoder_fault;
+__device__ unsigned g_decoder_fault_info[4];   // first give-up of the pipeline kernel: {1, workgroup, phase, cluster}
 
 #ifdef MMT_PROFILE
 // diagnostic build: wall-clock (100 MHz) stamps per launch / workgroup / stage, read by tools/cluster_profile.py
@@ -45,8 +46,17 @@ __device__ unsigned long long g_clprof[CLP_LAUNCHES][CLP_WGS][8];
 extern "C" int mmt_debug_read_clprof(unsigned long long *host, size_t n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clprof), sizeof(unsigned long long) * n);
 }
+// pipeline kernel: stamps per workgroup and visit (step * 16 + local cluster index), read by tools/pipe_profile.py
+#define PPR_WGS 256
+#define PPR_VISITS 192
+__device__ unsigned long long g_pprof[PPR_WGS][PPR_VISITS][16];
+#define PSTAMP(visit, k) do { if (thread_idx() == 0 && blockIdx.x < PPR_WGS && (visit) < PPR_VISITS) g_pprof[blockIdx.x][visit][k] = wall_clock64(); } while (0)
+extern "C" int mmt_debug_read_pprof(unsigned long long *host, size_t n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pprof), sizeof(unsigned long long) * n);
+}
 #else
 #define CSTAMP(k) do { } while (0)
+#define PSTAMP(visit, k) do { } while (0)
 #endif
 
 namespace {
@@ -67,7 +77,7 @@ enum { PH_A = 0, PH_B = 1, PH_C = 2, PH_H = 3 };
 struct ClArgs {
   int B, T, ph, d, H, RC, s, L, n_in, n_out, FS16, map_dim, has_map_fusion, prof_idx;
   int n_chain;                      // the small linears behind output_fc: fusion/hist_map then decoder/MLP
-  int pad0;
+  int tagged;                       // 4-agent-cluster kernels: rows handed from phase to phase carry the phase's tag bit (below)
   const float *part_in, *xres_in;
   float *part_out, *xres_out;
   const float *red_bias;
@@ -282,6 +292,35 @@ __device__ __forceinline__ void reduce_finish(const RedRegs &R, const ClArgs &a,
   }
 }
 
+// ---- tag bits (4-agent-cluster kernels) --------------------------------------------------------------------------------
+// Every row that one phase hands to the next (the H partial sums, the residual rows, the embedded token) has the two lowest
+// mantissa bits of each float REPLACED by a tag: (p >> 3) & 3 for phase p = step * 3L + 3 * layer + sub-layer (s & 3 for the
+// embedded token of step s).  The pipeline kernel rotates its hand-off rows over 8 slots (2 buffers x 4 row blocks of the
+// 16-row cluster slots, of which 4-agent clusters use only 4 rows), so consecutive contents of a slot carry consecutive tags,
+// and its consumers poll the DATA itself (no counter, no drain): a word is valid when it carries the expected tag and is not
+// the 0xFFFFFFFF the buffers are filled with before every decode.  A stage can start polling for a cluster at most 3L phases
+// before the rows are written (it has visited the cluster one step earlier): in that window a slot sees <= 3L/8 + 1 <= 4
+// generations (L <= 8), which 2 bits tell apart.  The tag is a deterministic change of <= 3 ulp of an intermediate sum; it
+// is applied by ALL 4-agent-cluster forms (launch-per-phase, fused, pipeline), which therefore stay bit-identical.
+constexpr unsigned TAG_MASK = 3u;
+__device__ __forceinline__ float tag1(float v, unsigned tag) {
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v) & ~TAG_MASK) | tag);
+}
+__device__ __forceinline__ f32x4 tag4(f32x4 v, unsigned tag) {
+  return (f32x4){tag1(v[0], tag), tag1(v[1], tag), tag1(v[2], tag), tag1(v[3], tag)};
+}
+__device__ __forceinline__ bool tag_ok(f32x4 v, unsigned tag) {
+  unsigned bad = 0;                      // branch-free: all four words of the 16-byte load are looked at
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned w = __builtin_bit_cast(unsigned, v[e]);
+    bad |= ((w ^ tag) & TAG_MASK) | (w == 0xFFFFFFFFu ? 1u : 0u);
+  }
+  return bad == 0;
+}
+__device__ __forceinline__ unsigned tag_of_phase(unsigned p) { return (p >> 3) & TAG_MASK; }
+__device__ __forceinline__ unsigned phase_tag(const ClArgs &a) { return tag_of_phase((unsigned)a.prof_idx); }   // prof_idx = phase p
+
 // x = tok W_in^T + b + pe[s]  (Transformer_model.py:100-102); tok is a 16x16 LDS tile (n_in <= 16)
 template <bool SC1 = false>
 __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const float *tok, float *xs, int ldx, bool write_res) {
@@ -297,10 +336,12 @@ __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const 
     const float add = a.input_fc.b[col] + a.pe[(size_t)a.s * a.d + col];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const float y = acc[rr] + add;
+      float y = acc[rr] + add;
+      if (a.tagged) y = tag1(y, (unsigned)a.s & TAG_MASK);            // the embedded token of step s
       xs[(row0 + rr) * ldx + col] = y;
       if (write_res && row0 + rr < a.RC) {
         float *dst = a.xres_out + ((size_t)cluster * 16 + row0 + rr) * a.d + col;
+        if (a.tagged) y = tag1(y, phase_tag(a));                      // as the residual row of this phase
         if constexpr (SC1) __hip_atomic_store((gf32 *)dst, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
         else *dst = y;
       }
@@ -704,7 +745,8 @@ __device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int 
   R.bet = bl4(mk_rsrc(a.red_ln.b), co);
 }
 template <int AUX = AUX_PLAIN>
-__device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res) {
+__device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res,
+                                               bool tag_rows = true) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
   f32x4 acc = R.res + R.bias;
@@ -721,6 +763,7 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
     f32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = (acc[e] - mu) * rstd * R.gam[e] + R.bet[e];
+    if (a.tagged && tag_rows) y = tag4(y, phase_tag(a));       // this phase's input = the next phase's residual rows
     *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = y;
     if (write_res) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + row) * a.d), (unsigned)q * 16u, y);
   }
@@ -769,6 +812,58 @@ __device__ __forceinline__ void main_issue4(MainRegs4<DH, PHASE> &M, const ClArg
 #pragma unroll
     for (int t = 0; t < G4::QMAX2; ++t)
       M.w2[t] = bl4s(r2, t < L2.q ? lane_off : OOB, t < L2.q ? (unsigned)(((g * L2.q + t) * 8 + w) * 1024) : 0u);
+  }
+}
+
+// the stationary part of a phase's operands: its weight slices and the first linear's bias (slice g)
+template <int DH, int PHASE>
+__device__ __forceinline__ void weights_issue4(MainRegs4<DH, PHASE> &M, const ClArgs &a, int g) {
+  typedef Geom4<PHASE> G4;
+  const int d = a.d, FS = a.FS16 * 16, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const unsigned lane_off = lane * 16u;
+  const Lin4 L1 = lin4((PHASE == PH_C ? FS : DH) / 4, d / 4);
+  const rsrc_t r1 = mk_rsrc(a.w1);
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p)
+#pragma unroll
+    for (int t = 0; t < G4::QMAX1; ++t)
+      M.w1[p][t] = bl4s(r1, t < L1.q ? lane_off : OOB, t < L1.q ? (unsigned)((((g * G4::NPART + p) * L1.q + t) * 8 + w) * 1024) : 0u);
+  {   // bias: the lanes of the first blocks write the result (block b -> part b in phase A, column group b else)
+    int bi;
+    if constexpr (PHASE == PH_A) bi = b * d + g * DH + w * 4 + j;
+    else if constexpr (PHASE == PH_B) bi = g * DH + w * 4 + j;
+    else bi = g * FS + (w * L1.cgw + b) * 4 + j;
+    M.b1 = bl1(mk_rsrc(a.b1), b < (PHASE == PH_C ? L1.cgw : G4::NPART) ? (unsigned)bi * 4u : OOB);
+  }
+  {   // second linear: all d output columns, K slice g of out_proj / linear2
+    const Lin4 L2 = lin4(d / 4, (PHASE == PH_C ? FS : DH) / 4);
+    const rsrc_t r2 = mk_rsrc(a.w2);
+#pragma unroll
+    for (int t = 0; t < G4::QMAX2; ++t)
+      M.w2[t] = bl4s(r2, t < L2.q ? lane_off : OOB, t < L2.q ? (unsigned)(((g * L2.q + t) * 8 + w) * 1024) : 0u);
+  }
+}
+// the per-(cluster, step) part: head g's K/V cache rows of the cluster's agents and the key-padding flags
+template <int DH, int PHASE, int AUX = AUX_PLAIN>
+__device__ __forceinline__ void kv_issue4(MainRegs4<DH, PHASE> &M, const ClArgs &a, int a0, int na, int g, int step = -1) {
+  const int d = a.d;
+  if constexpr (PHASE == PH_A || PHASE == PH_B) {
+    const int nglob = PHASE == PH_A ? (step >= 0 ? step : a.s) : a.T;
+    const float *base = a.kv + (((size_t)a.L * a.B + a0) * (PHASE == PH_A ? a.ph : a.T)) * 2 * d;
+    const unsigned astride = (unsigned)(PHASE == PH_A ? a.ph : a.T) * 2 * d;
+    const rsrc_t rkv = mk_rsrc(base);
+#pragma unroll
+    for (int it = 0; it < DH / 16; ++it) {
+      int ag, jj, kv, c4;
+      kv_unit<DH>(thread_idx() + CNT * it, ag, jj, kv, c4);
+      M.kv[it] = bl4x<AUX>(rkv, (ag < na && jj < nglob) ? (ag * astride + (unsigned)jj * 2 * d + kv * d + g * DH + 4 * c4) * 4u : OOB);
+    }
+  }
+  M.pad = 0;
+  if constexpr (PHASE == PH_B) {
+    const int ar = thread_idx() >> 4, l16 = thread_idx() & 15;
+    M.pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && ar < na && l16 < a.T)
+                                                    ? (unsigned)((a0 + ar) * a.T + l16) : OOB, 0, 0);
   }
 }
 
@@ -830,6 +925,7 @@ __device__ __forceinline__ void gemm2_4(const MainRegs4<DH, PHASE> &M, const ClA
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = kparts_sum(acc[r], L2.cgw);
   quad_transpose(acc, j);                            // lane j of a quad: row j, the quad's 4 columns -> one 16-byte store
+  if (a.tagged) acc = tag4(acc, phase_tag(a));
   bs4x<AUX>(mk_rsrc(part), b < L2.cgw ? (unsigned)(j * d + (w * L2.cgw + b) * 4) * 4u : OOB, acc);
 }
 
@@ -929,7 +1025,7 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
   }
 
   // ---- 2. input of this sub-layer
-  if (red_wave) reduce4_finish<AUX>(R, a, cluster, xs, ldx, g == 0 && !HEAD);
+  if (red_wave) reduce4_finish<AUX>(R, a, cluster, xs, ldx, g == 0 && !HEAD, !HEAD);
   if constexpr (HEAD) {
     head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur, FUSED ? pos : nullptr);
     main_issue4<DH, PHASE, AUX>(M, a, a0, na, g);
@@ -1133,6 +1229,519 @@ __global__ __launch_bounds__(CNT) void mmt_dec_fused4_kernel(FusedArgs f) {
   }
 }
 
+// ---- the same two linears with the geometry known at compile time (pipeline kernel): every LDS read of the activations is
+// issued before the first MFMA and the K-part sums are straight-line code.  Same products, same summation order as gemm1_4 /
+// gemm2_4 (bit-identical results).
+template <int CG, int KQ>
+struct Lin4S {
+  static constexpr int cgw = CG >> 3;
+  static constexpr int lg_cgw = cgw == 1 ? 0 : cgw == 2 ? 1 : cgw == 4 ? 2 : cgw == 8 ? 3 : 4;
+  static constexpr int q = (KQ >> (4 - lg_cgw)) < 1 ? 1 : (KQ >> (4 - lg_cgw));
+};
+template <int CGW>
+__device__ __forceinline__ float kparts_sum_s(float v) {
+  if constexpr (CGW <= 1) v += dpp_mov<0x124>(v);
+  if constexpr (CGW <= 2) v += dpp_mov<0x128>(v);
+  if constexpr (CGW <= 4) v = xor16_sum(v);
+  if constexpr (CGW <= 8) v = xor32_sum(v);
+  return v;
+}
+template <int DH, int PHASE, int D, int FS>
+__device__ __forceinline__ void gemm1_4s(const MainRegs4<DH, PHASE> &M, const float *xs, int ldx, float *t1, int ld1) {
+  typedef Geom4<PHASE> G4;
+  typedef Lin4S<(PHASE == PH_C ? FS : DH) / 4, D / 4> L1;
+  static_assert(L1::q <= G4::QMAX1, "first linear exceeds the register tile");
+  constexpr int KQ = D / 4;
+  const int w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const int kq0 = (b >> L1::lg_cgw) * L1::q;
+  const float *xr = xs + j * ldx;
+  f32x4 xv[L1::q];
+#pragma unroll
+  for (int t = 0; t < L1::q; ++t) xv[t] = *reinterpret_cast<const f32x4 *>(xr + 4 * min(kq0 + t, KQ - 1));
+  f32x4 acc[G4::NPART];
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < L1::q; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int p = 0; p < G4::NPART; ++p) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[t][e], M.w1[p][t][e], acc[p], 0, 0, 0);
+#pragma unroll
+  for (int p = 0; p < G4::NPART; ++p)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[p][r] = kparts_sum_s<L1::cgw>(acc[p][r]);
+  if constexpr (PHASE == PH_A) {
+    if (b < 3) {
+      const f32x4 v = b == 0 ? acc[0] : b == 1 ? acc[G4::NPART > 1 ? 1 : 0] : acc[G4::NPART > 2 ? 2 : 0];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t1[r * ld1 + b * DH + w * 4 + j] = v[r] + M.b1;
+    }
+  } else if (b < (PHASE == PH_C ? L1::cgw : 1)) {
+    const int col = (w * L1::cgw + b) * 4 + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t1[r * ld1 + col] = PHASE == PH_C ? fmaxf(acc[0][r] + M.b1, 0.f) : acc[0][r] + M.b1;
+  }
+}
+template <int DH, int PHASE, int D, int FS, int AUX>
+__device__ __forceinline__ void gemm2_4s(const MainRegs4<DH, PHASE> &M, const float *x2, int ld2, float *part, unsigned tag) {
+  typedef Geom4<PHASE> G4;
+  constexpr int K2q = (PHASE == PH_C ? FS : DH) / 4;
+  typedef Lin4S<D / 4, K2q> L2;
+  static_assert(L2::q <= G4::QMAX2, "second linear exceeds the register tile");
+  const int w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const int kq0 = (b >> L2::lg_cgw) * L2::q;
+  const float *xr = x2 + j * ld2;
+  f32x4 xv[L2::q];
+#pragma unroll
+  for (int t = 0; t < L2::q; ++t) xv[t] = *reinterpret_cast<const f32x4 *>(xr + 4 * min(kq0 + t, K2q - 1));
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < L2::q; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[t][e], M.w2[t][e], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = kparts_sum_s<L2::cgw>(acc[r]);
+  quad_transpose(acc, j);                            // lane j of a quad: row j, the quad's 4 columns -> one 16-byte store
+  acc = tag4(acc, tag);
+  bs4x<AUX>(mk_rsrc(part), b < L2::cgw ? (unsigned)(j * D + (w * L2::cgw + b) * 4) * 4u : OOB, acc);
+}
+
+// ------------------------------------------------------------------------------- weight-stationary pipeline (one launch)
+// The fused kernel above re-requests its 128 KB weight slice in every one of the 216 phases (0.9 us through one CU's address
+// path per phase, 2 GB per decode through the L2s).  Here a workgroup is bound to ONE (layer, sub-layer, slice) for the whole
+// decode and keeps that slice in registers (64 VGPRs per lane); the 4-agent clusters flow through the 3L + 1 stages:
+//   stage kinds per layer:  A  self attention,  H workgroups (one head each)
+//                           B  cross attention, H/2 workgroups (two heads each: half the weights of A / C per head)
+//                           C  feed forward,    H workgroups (d_ff/H hidden columns each)
+//   + head workgroups: reduce + LayerNorm of the last layer, output_fc, [fusion/hist_map], decoder/MLP, position feedback and
+//     the embedding of the next token (stage 0 of every step).
+// The whole pipeline is replicated R times (replica r owns the clusters m = r mod R) to fill the chip: 2 x (6 x 20 + 4) = 248
+// workgroups on 256 CUs at the shipped size.  Hand-offs, buffers and arithmetic are those of the fused kernel (bit-identical
+// outputs): phase p = step * (3L + 1) + stage writes part[p & 1] / xres[p & 1], reads the other pair, and may start on cluster m
+// once the cluster's arrival counter shows H * p (every stage adds H in total: A and C workgroups 1 each, B workgroups 2, the head
+// workgroup H).  A stage visits (step, cluster) in lexicographic order and depends only on the previous stage of the same
+// cluster, so with all workgroups resident nothing can dead-lock; every wait is bounded as in the fused kernel.
+struct PipeArgs {
+  ClArgs a;
+  FusedLayer layer[MMT_MAX_LAYERS];
+  float *part[2], *xres[2], *selfkv, *memkv;
+  unsigned *sync;                              // [0]: time-out word
+  float *x0buf;                                // [cluster][4][d]: the embedded token of the current step, head -> first stage
+  const float *head_bias;                      // what the head stage's reduction adds / normalises with: the last layer's
+  mmt_norm head_ln;                            //   linear2 bias and norm3
+  int nlayers, test_stall, R, NHW, NC, pad_;
+};
+constexpr int PIPE_MAXPOS = 16;                // clusters whose last positions a head workgroup keeps in LDS (others: pred_st)
+
+struct PipeLds {
+  float *xs, *red, *ha, *hb, *tok, *t1, *ob, *ps, *Ks, *Vs, *pos;
+  int *abort;
+};
+template <int DH>
+__host__ __device__ __forceinline__ size_t pipe_lds_floats(int d) {
+  constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
+  return (size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 2 * 16 * LDO + 16 * LDTOK + 2 * 4 * LD1 + 2 * 4 * LDO + 256 +
+         2 * (2 * 4 * KMAX * LDK) + PIPE_MAXPOS * 64;
+}
+template <int DH>
+__device__ __forceinline__ PipeLds pipe_lds(float *smem, int d) {
+  constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
+  PipeLds L;
+  L.xs = smem;                                   // [16][ldx]  rows 0..3: input of the sub-layer (16 rows where the head runs)
+  L.red = L.xs + 16 * (d + MMT_PAD);             // K-split partial tiles of the head's small linears
+  L.ha = L.red + CNW * KS_SMAX * 256;
+  L.hb = L.ha + 16 * LDO;
+  L.tok = L.hb + 16 * LDO;
+  L.t1 = L.tok + 16 * LDTOK;                     // [2][4][LD1]  q|k|v of a head, or the FFN hidden slice
+  L.ob = L.t1 + 2 * 4 * LD1;                     // [2][4][LDO]  attention output of a head
+  L.ps = L.ob + 2 * 4 * LDO;                     // [2][64]      attention probabilities
+  L.abort = reinterpret_cast<int *>(L.ps + 128);
+  L.Ks = L.ps + 256;                             // [2][4][KMAX][LDK]
+  L.Vs = L.Ks + 2 * 4 * KMAX * LDK;
+  L.pos = L.Vs + 2 * 4 * KMAX * LDK;             // [PIPE_MAXPOS][4][16]
+  return L;
+}
+
+// ---- data-tagged hand-off (see "tag bits" above): the consumer's red waves poll the rows themselves --------------------------
+constexpr unsigned long long PIPE_WAIT_TICKS = 20000000ull;     // 0.2 s of the 100 MHz wall clock: a wait this long = give up
+struct PipeSync {
+  gu32 *tmo;             // time-out word of the launch (global)
+  int *abort;            // LDS
+};
+// give up: raise the launch's time-out word (every other workgroup follows at its next check) and this workgroup's abort flag
+__device__ __forceinline__ void pipe_give_up(const PipeSync &ps, int phase, int cluster) {
+  if (atomicCAS(&g_decoder_fault_info[0], 0u, 1u) == 0u) {      // the first one to give up says where (mmt_decoder_status)
+    g_decoder_fault_info[1] = blockIdx.x;
+    g_decoder_fault_info[2] = (unsigned)phase;
+    g_decoder_fault_info[3] = (unsigned)cluster;
+  }
+  __hip_atomic_store(ps.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *ps.abort = 1;
+}
+// One wave (row `row` of cluster's 4) fetches what the previous phase left for it - residual row and the H partial rows, or (x0)
+// the embedded token - and re-fetches until every word carries the expected tag.  The first two attempts take everything (in the
+// steady state the rows are there or land within a round trip); after that only one 16-byte piece per lane is polled, with
+// s_sleep, so that idle stages do not load the memory system.  Returns false when it gave up (wave-uniform).
+template <bool X0>
+__device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const float *x0buf, int cluster, unsigned tag, const PipeSync &ps) {
+  const int row = wave_id(), q = lane_id();
+  const bool live = q < (a.d >> 2);
+  const unsigned co = live ? (unsigned)q * 16u : OOB, gstride = 16u * a.d * 4u;
+  const rsrc_t res = mk_rsrc(X0 ? x0buf + ((size_t)cluster * 4 + row) * a.d : a.xres_in + ((size_t)cluster * 16 + row) * a.d);
+  const rsrc_t pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
+  unsigned long long t0 = 0;
+  for (int tries = 0;; ++tries) {
+    asm volatile("" ::: "memory");       // the loads below are re-issued every pass (buffer loads are not volatile to the compiler)
+    R.res = bl4x<AUX_SC1>(res, co);
+    bool ok = !live || tag_ok(R.res, tag);
+    if constexpr (!X0) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        R.p[g] = bl4x<AUX_SC1>(pp, g < a.H ? co : OOB, g < a.H ? g * gstride : 0u);
+        ok = ok && (g >= a.H || !live || tag_ok(R.p[g], tag));
+      }
+    }
+    if (__all(ok)) return true;
+    if (tries > 64 && (tries & 63) == 0 && t0 && wall_clock64() - t0 > PIPE_WAIT_TICKS) {
+      if (q == 0) pipe_give_up(ps, a.prof_idx, cluster);
+      return false;
+    }
+#ifndef MMT_PIPE_FULL_POLLS
+#define MMT_PIPE_FULL_POLLS 2
+#endif
+    if (tries >= MMT_PIPE_FULL_POLLS - 1) {                    // thin polling: the last partial row (or the token row) only
+      if (!t0) t0 = wall_clock64();
+      for (unsigned n = 0;; ++n) {
+        __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+        const f32x4 v = X0 ? bl4x<AUX_SC1>(res, co) : bl4x<AUX_SC1>(pp, co, (unsigned)(a.H - 1) * gstride);
+        if (__all(!live || tag_ok(v, tag))) break;
+        if ((n & 15u) == 15u &&
+            (__hip_atomic_load(ps.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > PIPE_WAIT_TICKS)) {
+          if (q == 0 && wall_clock64() - t0 > PIPE_WAIT_TICKS) pipe_give_up(ps, a.prof_idx + (X0 ? 100000 : 0) + 1000 * row, cluster);
+          else if (q == 0) *ps.abort = 1;
+          return false;
+        }
+      }
+    }
+  }
+}
+
+// attention of one head for the 4 agents of a cluster, on ONE wave: one (agent, key) pair per lane; phase A takes the key / value
+// of this step from t1 (same arithmetic, same order as phase4_body)
+template <int DH, int PHASE>
+__device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const float *t1, int ld1, const float *Ks, const float *Vs,
+                                        float *ps, float *ob, int visit = 0) {
+  constexpr int LDK = DH + 4;
+  const int nglob = PHASE == PH_A ? a.s : a.T;
+  const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
+  const int lane = lane_id(), ar = lane >> 4, l16 = lane & 15;
+  float sc = -INFINITY;
+  bool masked = ar >= na || l16 >= nkeys;
+  if constexpr (PHASE == PH_B) masked = masked || pad != 0;
+  if (!masked) {
+    const float *q = t1 + ar * ld1;
+    const float *k = (PHASE == PH_A && l16 == nglob) ? q + DH : Ks + (ar * KMAX + l16) * LDK;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 4; ++c) {
+      const f32x4 qv = *reinterpret_cast<const f32x4 *>(q + 4 * c), kv4 = *reinterpret_cast<const f32x4 *>(k + 4 * c);
+      acc = fmaf(qv[0], kv4[0], acc);
+      acc = fmaf(qv[1], kv4[1], acc);
+      acc = fmaf(qv[2], kv4[2], acc);
+      acc = fmaf(qv[3], kv4[3], acc);
+    }
+    sc = acc * (1.0f / sqrtf((float)DH));
+  }
+  PSTAMP(visit, 8);
+  const float mx = row16_max(sc);
+  float p = mx > -INFINITY ? expf(sc - mx) : 0.f;    // a fully masked row yields zeros (reference: undefined / NaN)
+  const float sum = row16_sum(p);
+  p *= sum > 0.f ? 1.0f / sum : 0.f;
+  ps[lane] = p;
+  PSTAMP(visit, 9);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ps is written and read by this wave only
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int DPL = DH / 16;
+  float o[DPL];
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+  const int nk = ar < na ? nglob : 0;
+  // all LDS reads in flight at once (a loop with a run-time trip count pays one LDS round trip per key), then the same
+  // fused multiply-adds in the same order; rows beyond nk hold stale bits and are never multiplied
+  typedef float vrow __attribute__((ext_vector_type(DPL)));
+  f32x4 pr[KMAX / 4];
+  vrow vv[KMAX];
+#pragma unroll
+  for (int c = 0; c < KMAX / 4; ++c) pr[c] = *reinterpret_cast<const f32x4 *>(ps + ar * 16 + 4 * c);
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) vv[j] = *reinterpret_cast<const vrow *>(Vs + (ar * KMAX + j) * LDK + l16 * DPL);
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    const float pj = pr[j >> 2][j & 3];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) o[e] = j < nk ? fmaf(pj, vv[j][e], o[e]) : o[e];
+  }
+  if (PHASE == PH_A && ar < na) {
+    const float pj = ps[ar * 16 + nglob];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, t1[ar * ld1 + 2 * DH + l16 * DPL + e], o[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) ob[ar * LDO + l16 * DPL + e] = o[e];
+  PSTAMP(visit, 10);
+}
+
+// One visit of a stage workgroup to one cluster: NH heads / slices starting at g0, weights already in M.
+// kv_ready: M[].kv / pad already hold this visit's K/V cache rows (requested during the previous visit); nx_*: the next visit,
+// whose rows are requested behind this visit's attention (nx_cluster < 0: none, or they are not final yet).
+template <int DH, int PHASE, int NH, int D, int FS>
+__device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, int cluster, int g0, bool loadx, const PipeLds &S,
+                                           const PipeSync &ps, MainRegs4<DH, PHASE> (&M)[NH], int &pad, bool kv_ready, int nx_step,
+                                           int nx_cluster, int visit) {
+  constexpr int AUX = AUX_SC1;
+  constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
+  const int d = a.d, ldx = d + MMT_PAD, tid = thread_idx();
+  const int a0 = cluster * 4, na = min(4, a.B - a0);
+  const unsigned tag_out = phase_tag(a), tag_in = tag_of_phase((unsigned)a.prof_idx - 1u);
+  PSTAMP(visit, 0);
+  auto kv_request = [&](int cl, int step) {
+    const int b0 = cl * 4, nb = min(4, a.B - b0);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) kv_issue4<DH, PHASE, AUX_PLAIN>(M[h], a, b0, nb, g0 + h, step);
+    if constexpr (PHASE == PH_B) {
+      const int ar = lane_id() >> 4, l16 = lane_id() & 15;
+      pad = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad_mask), (a.pad_mask && wave_id() < NH && ar < nb && l16 < a.T)
+                                                    ? (unsigned)((b0 + ar) * a.T + l16) : OOB, 0, 0);
+    }
+  };
+  // ---- 0. this cluster's K/V cache rows do not depend on the previous phase: requested first, staged once the poll is through
+  if (!kv_ready) {
+    if constexpr (PHASE == PH_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's earlier cache appends have left
+    kv_request(cluster, a.s);
+  }
+  // ---- 1. the previous phase's rows, polled until they carry its tag
+  Red4Regs R;
+  const bool red_wave = wave_id() < 4;
+  bool got = true;
+  if (red_wave) {
+    if (!loadx) {
+      const unsigned co = lane_id() < (d >> 2) ? (unsigned)lane_id() * 16u : OOB;
+      R.bias = bl4(mk_rsrc(a.red_bias), co);
+      R.gam = bl4(mk_rsrc(a.red_ln.g), co);
+      R.bet = bl4(mk_rsrc(a.red_ln.b), co);
+    }
+    got = loadx ? poll_rows<true>(R, a, x0buf, cluster, (unsigned)a.s & TAG_MASK, ps) : poll_rows<false>(R, a, x0buf, cluster, tag_in, ps);
+  }
+  (void)got;                                           // a wave that gave up has raised the abort flag
+  PSTAMP(visit, 1);
+  // ---- 2. input of this sub-layer
+  if (red_wave) {
+    if (loadx) {
+      if (lane_id() < (d >> 2)) {
+        *reinterpret_cast<f32x4 *>(S.xs + wave_id() * ldx + 4 * lane_id()) = R.res;
+        if (g0 == 0) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + wave_id()) * d), (unsigned)lane_id() * 16u, tag4(R.res, tag_out));
+      }
+    } else {
+      reduce4_finish<AUX>(R, a, cluster, S.xs, ldx, g0 == 0);
+    }
+  }
+  // K/V cache rows (the self-attention cache was appended by this very workgroup in earlier steps): registers -> staging tiles
+  if constexpr (PHASE != PH_C) {
+    const int nglob = PHASE == PH_A ? a.s : a.T;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int it = 0; it < DH / 16; ++it) {
+        int ag, j, kv, c4;
+        kv_unit<DH>(tid + CNT * it, ag, j, kv, c4);
+        if (ag < na && j < nglob)
+          *reinterpret_cast<f32x4 *>((kv ? S.Vs : S.Ks) + ((h * 4 + ag) * KMAX + j) * LDK + 4 * c4) = M[h].kv[it];
+      }
+  }
+  const int pad_now = pad;
+  PSTAMP(visit, 11);
+  __syncthreads();
+  if (*ps.abort) return false;
+  PSTAMP(visit, 2);
+  // ---- 3. first linear
+#pragma unroll
+  for (int h = 0; h < NH; ++h) gemm1_4s<DH, PHASE, D, FS>(M[h], S.xs, ldx, S.t1 + h * 4 * LD1, LD1);
+  PSTAMP(visit, 7);
+  __syncthreads();
+  PSTAMP(visit, 3);
+  // ---- 4. attention: wave h serves head g0 + h
+  if constexpr (PHASE != PH_C) {
+    if (wave_id() < NH) {
+      const int h = wave_id();
+      attend4<DH, PHASE>(a, na, pad_now, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
+                         S.ob + h * 4 * LDO, visit);
+    } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read back by this workgroup only)
+      const int i = tid - 256;
+      if (i < na * 2 * (DH / 4)) {
+        const int r = i / (2 * (DH / 4)), rem = i - r * 2 * (DH / 4), kv = rem / (DH / 4), c4 = rem - kv * (DH / 4);
+        *reinterpret_cast<f32x4 *>(a.kv + (((size_t)a.L * a.B + a0 + r) * a.ph + a.s) * 2 * d + kv * d + g0 * DH + 4 * c4) =
+            *reinterpret_cast<const f32x4 *>(S.t1 + r * LD1 + (1 + kv) * DH + 4 * c4);
+      }
+    }
+    // the next visit's K/V cache rows: requested now, staged at the start of that visit (a memory round trip off its path)
+    if (nx_cluster >= 0) {
+      if constexpr (PHASE == PH_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      kv_request(nx_cluster, nx_step);
+    }
+    __syncthreads();
+  }
+  PSTAMP(visit, 4);
+  // ---- 5. K-slices of the output projection: one tagged partial [4][d] per head / slice, write-through, nothing to wait for
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+    gemm2_4s<DH, PHASE, D, FS, AUX>(M[h], PHASE == PH_C ? S.t1 : S.ob + h * 4 * LDO, PHASE == PH_C ? LD1 : LDO,
+                                    a.part_out + ((size_t)cluster * a.H + g0 + h) * 16 * d, tag_out);
+  PSTAMP(visit, 5);
+  PSTAMP(visit, 6);
+  return true;
+}
+
+template <int DH, int PHASE, int NH, int D, int FS>
+__device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0, int replica, const PipeLds &S, const PipeSync &ps) {
+  static_assert(PHASE != PH_A || NH == 1, "the K/V cache append serves one head");
+  ClArgs a = f.a;
+  const FusedLayer &W = f.layer[layer];
+  a.L = layer;
+  a.w1 = W.w1[PHASE];
+  a.b1 = W.b1[PHASE];
+  a.w2 = W.w2[PHASE];
+  a.red_bias = W.red_bias[PHASE];
+  a.red_ln = W.red_ln[PHASE];
+  a.kv = PHASE == PH_A ? f.selfkv : f.memkv;
+  MainRegs4<DH, PHASE> M[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    M[h] = {};
+    weights_issue4<DH, PHASE>(M[h], a, g0 + h);      // ONCE: the slice stays in registers for the whole decode
+  }
+  const int NP = 3 * f.nlayers, k = 3 * layer + PHASE;
+  const bool loadx = PHASE == PH_A && layer == 0;    // the first stage takes the embedded token as it is (no reduction, no LayerNorm)
+  // the K/V rows of the next visit are requested a visit ahead unless that visit is to the same cluster (then the row appended
+  // in this visit would be missing)
+  const bool ahead = false && PHASE != PH_C && replica + f.R < f.NC;     // (measured: no gain - the hand-off round trip covers the loads)
+  int pad = 0;
+  bool kv_ready = false;
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < f.a.ph; ++s) {
+    const unsigned p = (unsigned)(s * NP + k);
+    a.s = s;
+    a.prof_idx = (int)p;
+    // slot of phase q: buffer q & 1, row block ((p_last - q) >> 1) & 3 of the 16-row cluster slots (period 8; the last phase of the
+    // decode lands in rows 0..3, where the final head launch looks for it)
+    const unsigned p_last = (unsigned)(NP * f.a.ph - 1);
+    const size_t rb_out = (size_t)4 * (((p_last - p) >> 1) & 3u) * f.a.d, rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
+    a.part_out = f.part[p & 1] + rb_out;
+    a.xres_out = f.xres[p & 1] + rb_out;
+    a.part_in = f.part[(p + 1) & 1] + rb_in;
+    a.xres_in = f.xres[(p + 1) & 1] + rb_in;
+    int li = 0;
+#pragma clang loop unroll(disable)
+    for (int m = replica; m < f.NC; m += f.R, ++li) {
+      if (f.test_stall && s == 1 && layer == 1 && PHASE == PH_B && g0 == 0 && m == replica) return;   // its successors must time out
+      int nx_cluster = -1, nx_step = s;
+      if (ahead) {
+        if (m + f.R < f.NC) nx_cluster = m + f.R;
+        else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
+      }
+      if (!pipe_phase<DH, PHASE, NH, D, FS>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 16 + li)) return;
+      kv_ready = nx_cluster >= 0;
+    }
+  }
+}
+
+// The head workgroups: head of the previous step (s > 0) and embedding of the next token, for the clusters
+// replica + R * (j + NHW * i), i = 0, 1, ...  The token rows go to x0buf (tag s & 1), a buffer of their own.
+template <int CPW>
+__device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j, const PipeLds &S, const PipeSync &ps) {
+  ClArgs a = f.a;
+  const int d = a.d, ldx = d + MMT_PAD, K16 = d >> 4, tid = thread_idx();
+  a.red_bias = f.head_bias;
+  a.red_ln = f.head_ln;
+  const int NP = 3 * f.nlayers;
+  KsW<4, CPW> wo = {};
+  KsW<4, 1> sm0 = {};
+  ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });     // resident for the whole decode
+  if (!a.tgt) small_load(sm0, a.chain[0]);
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < f.a.ph; ++s) {
+    const unsigned p = (unsigned)(s * NP);           // the phase this step's first stage runs as; the head consumes phase p - 1
+    a.s = s;
+    a.prof_idx = (int)p;
+    const unsigned p_last = (unsigned)(NP * f.a.ph - 1);
+    const size_t rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
+    a.part_in = f.part[(p + 1) & 1] + rb_in;
+    a.xres_in = f.xres[(p + 1) & 1] + rb_in;
+    int li = 0;
+#pragma clang loop unroll(disable)
+    for (int m = replica + j * f.R; m < f.NC; m += f.R * f.NHW, ++li) {
+      const int a0 = m * 4, na = min(4, a.B - a0);
+      PSTAMP(s * 16 + li, 0);
+      Red4Regs R;
+      const bool red_wave = s > 0 && wave_id() < 4;
+      if (red_wave) {
+        const unsigned co = lane_id() < (d >> 2) ? (unsigned)lane_id() * 16u : OOB;
+        R.bias = bl4(mk_rsrc(a.red_bias), co);
+        R.gam = bl4(mk_rsrc(a.red_ln.g), co);
+        R.bet = bl4(mk_rsrc(a.red_ln.b), co);
+      }
+      for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) S.ha[i] = 0.f;      // the head's tiles and the token tile: finite
+      if (tid >= 256)                                                                   // rows 4..15 of the head's input tile
+        for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
+          *reinterpret_cast<f32x4 *>(S.xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (red_wave) (void)poll_rows<false>(R, a, f.x0buf, m, tag_of_phase(p - 1u), ps);
+      PSTAMP(s * 16 + li, 1);
+      __syncthreads();
+      if (*ps.abort) return;
+      if (red_wave) reduce4_finish<AUX_SC1>(R, a, m, S.xs, ldx, false, false);
+      if (s > 0) head_step<CPW>(a, 0, a0, na, S.xs, ldx, S.red, S.ha, S.hb, S.tok, wo, sm0, li < PIPE_MAXPOS ? S.pos + li * 64 : nullptr);
+      if (a.tgt || s == 0)
+        for (int i = tid; i < na * a.n_in; i += CNT) {
+          const int r = i / a.n_in, c = i - r * a.n_in;
+          S.tok[r * LDTOK + c] = a.tgt ? a.tgt[((size_t)(a0 + r) * a.ph + s) * a.n_in + c] : a.start_pos[(size_t)(a0 + r) * a.n_in + c];
+        }
+      __syncthreads();
+      PSTAMP(s * 16 + li, 4);
+      embed_token<false>(a, m, S.tok, S.xs, ldx, false);      // rows tagged s & 1
+      __syncthreads();
+      PSTAMP(s * 16 + li, 5);
+      if (wave_id() < 4 && lane_id() < (d >> 2))       // the embedded token, write-through, 16 bytes per lane
+        bs4x<AUX_SC1>(mk_rsrc(f.x0buf + ((size_t)m * 4 + wave_id()) * d), (unsigned)lane_id() * 16u,
+                      *reinterpret_cast<const f32x4 *>(S.xs + wave_id() * ldx + 4 * lane_id()));
+      __syncthreads();                                  // xs is rewritten by the next visit
+      PSTAMP(s * 16 + li, 6);
+    }
+  }
+}
+
+template <int DH, int CPW, int D, int FS>
+__global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
+  extern __shared__ __align__(16) float smem[];
+  const PipeLds S = pipe_lds<DH>(smem, f.a.d);
+  const int H = f.a.H, per_layer = 2 * H + H / 2, per_rep = f.nlayers * per_layer + f.NHW;
+  const int replica = blockIdx.x / per_rep, rb = blockIdx.x - replica * per_rep;
+  PipeSync ps;
+  ps.tmo = (gu32 *)f.sync;
+  ps.abort = S.abort;
+  if (thread_idx() == 0) *ps.abort = 0;
+  __syncthreads();
+  if (rb < f.nlayers * per_layer) {
+    const int layer = rb / per_layer, q = rb - layer * per_layer;
+    if (q < H) pipe_stage<DH, PH_A, 1, D, FS>(f, layer, q, replica, S, ps);
+    else if (q < H + H / 2) pipe_stage<DH, PH_B, 2, D, FS>(f, layer, 2 * (q - H), replica, S, ps);
+    else pipe_stage<DH, PH_C, 1, D, FS>(f, layer, q - H - H / 2, replica, S, ps);
+  } else {
+    pipe_head<CPW>(f, replica, rb - f.nlayers * per_layer, S, ps);
+  }
+}
+
 // ------------------------------------------------------------------------------- prologue kernels
 struct CkvArgs {
   int rows, d, L, B, T, ldx, ldb;
@@ -1140,6 +1749,8 @@ struct CkvArgs {
   float *memkv;              // [L][rows][2d]
   unsigned *sync;            // fused kernel's time-out word + arrival counters: zeroed here, one launch ahead of their use
   int nsync;
+  unsigned *fill[2];         // pipeline kernel: the hand-off buffers, filled with 0xFFFFFFFF (= "nothing here yet") before every decode
+  int nfill[2];
   mmt_linear ckv[MMT_MAX_LAYERS];
 };
 // cross-attention K/V of every layer (computed once per decode; the reference redoes it every step)
@@ -1150,6 +1761,15 @@ __global__ __launch_bounds__(CNT) void mmt_dec_ckv_kernel(CkvArgs a) {
   const int r0 = blockIdx.x * 16, nr = min(16, a.rows - r0);
   if (blockIdx.x == 0 && L == 0)
     for (int i = tid; i < a.nsync; i += CNT) a.sync[i] = 0u;
+  {
+    const int nb = gridDim.x * gridDim.y, bi = blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int n4 = a.nfill[k] >> 2;                         // whole float4s (the buffers are multiples of 4 floats)
+      u32x4 *dst = reinterpret_cast<u32x4 *>(a.fill[k]);
+      for (int i = bi * CNT + tid; i < n4; i += nb * CNT) dst[i] = (u32x4){0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    }
+  }
   for (int i = tid; i < 16 * (a.ldx + a.ldb); i += CNT) smem[i] = 0.f;
   __syncthreads();
   for (int i = tid; i < nr * (d >> 2); i += CNT) {
@@ -1201,8 +1821,9 @@ int mlp_width(const mmt_mlp &m) {
 // Environment knobs, read ONCE (first use): MMT_CLUSTER_ROWS=4|8|16, MMT_NO_MFMA4, MMT_NO_FUSED_DECODER.
 struct DecEnv {
   int cluster_rows;
-  bool no_mfma4, no_fused;
-  DecEnv() : cluster_rows(0), no_mfma4(getenv("MMT_NO_MFMA4") != nullptr), no_fused(getenv("MMT_NO_FUSED_DECODER") != nullptr) {
+  bool no_mfma4, no_fused, no_pipe;
+  DecEnv() : cluster_rows(0), no_mfma4(getenv("MMT_NO_MFMA4") != nullptr), no_fused(getenv("MMT_NO_FUSED_DECODER") != nullptr),
+             no_pipe(getenv("MMT_NO_PIPELINE_DECODER") != nullptr) {
     if (const char *e = getenv("MMT_CLUSTER_ROWS")) {
       const int v = atoi(e);
       if (v == 4 || v == 8 || v == 16) cluster_rows = v;
@@ -1379,7 +2000,26 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
   const int RC = cluster_rows(B, dec->nhead);
   const size_t NC = (B + RC - 1) / RC, d = dec->d_model;
   // + the fused kernel's time-out word and per-cluster arrival counters, one 128-byte line each (32 floats of slack to align them)
-  return NC * 16 * d * (2 * (size_t)dec->nhead + 2) + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64 + (NC + 2) * 32;
+  // ... and the pipeline kernel's token buffer [NC][4][d]
+  return NC * 16 * d * (2 * (size_t)dec->nhead + 2) + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64 + (NC + 2) * 32 + NC * 4 * d + 32;
+}
+
+enum { ONE_LAUNCH_NONE = 0, ONE_LAUNCH_FUSED = 1, ONE_LAUNCH_PIPE = 2 };
+struct PipeGeom {
+  int R, NHW, grid;     // replicas of the pipeline, head workgroups per replica, workgroups in all
+  float *x0buf;
+};
+// Replicas / head workgroups that fit on `ncu` CUs (one workgroup per CU); R = 0: the pipeline does not fit.
+static PipeGeom pipe_geom(int L, int H, int NC, int ncu) {
+  PipeGeom g = {0, 0, 0, nullptr};
+  if (H < 2 || (H & 1)) return g;
+  const int per_stage = L * (2 * H + H / 2);
+  g.R = std::min(NC, ncu / (per_stage + 1));
+  if (g.R < 1) return g;
+  const int per_rep_clusters = (NC + g.R - 1) / g.R;
+  g.NHW = std::max(1, std::min(std::min((ncu - g.R * per_stage) / g.R, 4), per_rep_clusters));
+  g.grid = g.R * (per_stage + g.NHW);
+  return g;
 }
 
 #define CL_CHECK(what)                                                                     \
@@ -1390,7 +2030,8 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
 
 template <int DH, int CPW, bool M4>
 static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], float *memkv, float *selfkv,
-                         unsigned *sync, bool fused, hipStream_t st) {
+                         unsigned *sync, int one_launch, const PipeGeom &pg, hipStream_t st) {
+  const bool fused = one_launch != ONE_LAUNCH_NONE;
   const int d = dec->d_model, H = dec->nhead, NC = (B + a.RC - 1) / a.RC, L = dec->nlayers;
   constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
   const size_t lds_c = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256) * sizeof(float);
@@ -1413,8 +2054,12 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
     SET_LDS(PH_C, XM_REDUCE, lds_c);
     SET_LDS(PH_H, XM_REDUCE, lds_c);
 #undef SET_LDS
-    if constexpr (M4)
+    if constexpr (M4) {
       (void)hipFuncSetAttribute((const void *)mmt_dec_fused4_kernel<DH, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+      if constexpr (DH == 32 && CPW == 2)
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+    }
     ds.attr_mask.fetch_or(fam_bit, std::memory_order_release);
   }
 #define LAUNCH_PHASE(PHASE, XM, BYTES)                                                                     \
@@ -1435,25 +2080,50 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   const dim3 grid(NC * H), blk(CNT);
   if constexpr (M4) {
     if (fused) {
-      FusedArgs f;
-      memset(&f, 0, sizeof(f));
-      f.a = a;
+      FusedLayer FL[MMT_MAX_LAYERS];
+      memset(FL, 0, sizeof(FL));
       for (int l = 0; l < L; ++l) {
         const mmt_dec_layer &W = dec->layer[l];
         const mmt_dec_layer &prev = l == 0 ? last : dec->layer[l - 1];
-        FusedLayer &F = f.layer[l];
+        FusedLayer &F = FL[l];
         F.w1[PH_A] = W.qkv4, F.b1[PH_A] = W.qkv.b, F.w2[PH_A] = W.out4, F.red_bias[PH_A] = prev.ff2.b, F.red_ln[PH_A] = prev.ln3;
         F.w1[PH_B] = W.cq4, F.b1[PH_B] = W.cq.b, F.w2[PH_B] = W.cout4, F.red_bias[PH_B] = W.out.b, F.red_ln[PH_B] = W.ln1;
         F.w1[PH_C] = W.ff14, F.b1[PH_C] = W.ff1.b, F.w2[PH_C] = W.ff24, F.red_bias[PH_C] = W.cout.b, F.red_ln[PH_C] = W.ln2;
       }
-      for (int i = 0; i < 2; ++i) f.part[i] = part[i], f.xres[i] = xres[i];
-      f.selfkv = selfkv;
-      f.memkv = memkv;
-      f.sync = sync;
-      f.nlayers = L;
-      f.test_stall = g_test_stall.load(std::memory_order_relaxed);
-      hipLaunchKernelGGL((mmt_dec_fused4_kernel<DH, CPW>), grid, blk, lds_a, st, f);
-      p = 3 * L * ph;
+      if (one_launch == ONE_LAUNCH_PIPE) {
+        PipeArgs f;
+        memset(&f, 0, sizeof(f));
+        f.a = a;
+        memcpy(f.layer, FL, sizeof(FL));
+        for (int i = 0; i < 2; ++i) f.part[i] = part[i], f.xres[i] = xres[i];
+        f.selfkv = selfkv;
+        f.memkv = memkv;
+        f.sync = sync;
+        f.x0buf = pg.x0buf;
+        f.head_bias = last.ff2.b;
+        f.head_ln = last.ln3;
+        f.nlayers = L;
+        f.test_stall = g_test_stall.load(std::memory_order_relaxed);
+        f.R = pg.R;
+        f.NHW = pg.NHW;
+        f.NC = NC;
+        if constexpr (DH == 32 && CPW == 2)      // the pipeline is built for the shipped geometry (pipe_geom_ok): d = 256, d_ff / H = 64
+          hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64>), dim3(pg.grid), blk, pipe_lds_floats<32>(256) * sizeof(float), st, f);
+        p = 3 * L * ph;
+      } else {
+        FusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.a = a;
+        memcpy(f.layer, FL, sizeof(FL));
+        for (int i = 0; i < 2; ++i) f.part[i] = part[i], f.xres[i] = xres[i];
+        f.selfkv = selfkv;
+        f.memkv = memkv;
+        f.sync = sync;
+        f.nlayers = L;
+        f.test_stall = g_test_stall.load(std::memory_order_relaxed);
+        hipLaunchKernelGGL((mmt_dec_fused4_kernel<DH, CPW>), grid, blk, lds_a, st, f);
+        p = 3 * L * ph;
+      }
       a.tmo = sync;
     }
   }
@@ -1501,14 +2171,17 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 }
 
 // The one-launch kernel spins on its siblings: it is only started when the occupancy query says the whole grid is resident.
-static bool fused_grid_fits(bool cpw2, int grid, int ncu, int d) {
+static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d) {
   constexpr int DH = 32;
   constexpr int LD1 = 3 * DH + 8;
-  const size_t lds = ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256 +
-                      (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
+  const size_t lds = pipe ? pipe_lds_floats<DH>(d) * sizeof(float)
+                          : ((size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 16 * LD1 + 3 * 16 * LDO + 16 * LDTOK + 256 +
+                             (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
   int per_cu = 0;
-  const hipError_t e = cpw2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 2>, CNT, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 1>, CNT, lds);
+  hipError_t e;
+  if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64>, CNT, lds);
+  else e = cpw2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 2>, CNT, lds)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 1>, CNT, lds);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return false;
@@ -1525,11 +2198,16 @@ extern "C" int mmt_decoder_status(void *stream) {
   if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_status: %s", hipGetErrorString(e));
   if (!v) return MMT_OK;
   const unsigned zero = 0;
+  unsigned info[4] = {0, 0, 0, 0};
+  (void)hipMemcpyFromSymbol(info, HIP_SYMBOL(g_decoder_fault_info), sizeof(info));
+  const unsigned zero4[4] = {0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_decoder_fault_info), zero4, sizeof(zero4));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_decoder_fault), &zero, sizeof(zero));
   g_dev[cur_dev()].fused_disabled.store(true, std::memory_order_relaxed);
   return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_forward: a one-launch decode on this device gave up waiting for a workgroup of "
                                     "its cluster (GPU shared or CU-masked?); that call's outputs are NaN.  The one-launch form is "
-                                    "now disabled on this device: re-issue the call (it runs launch-per-phase)");
+                                    "now disabled on this device: re-issue the call (it runs launch-per-phase) [first give-up: "
+                                    "workgroup %u phase %u cluster %u]", info[1], info[2], info[3]);
 }
 extern "C" int mmt_debug_decoder_stall(int on) {
   g_test_stall.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -1541,7 +2219,7 @@ extern "C" int mmt_debug_decoder_stall(int on) {
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                bool allow_fused, void *stream) {
+                                int allow_fused, void *stream) {      // 0: launch per phase, 1: fused kernel, 2: pipeline, 3: best
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d_model, H = dec->nhead, L = dec->nlayers;
   const int RC = cluster_rows(B, H), NC = (B + RC - 1) / RC;
@@ -1556,15 +2234,23 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   float *fused = xres[1] + (size_t)NC * 16 * d;
   float *after = fused + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64;
   unsigned *sync = reinterpret_cast<unsigned *>((reinterpret_cast<uintptr_t>(after) + 127) & ~(uintptr_t)127);
+  float *x0buf = reinterpret_cast<float *>(sync + (size_t)(NC + 1) * 32);
   // One launch for all phases when every workgroup of the decode is resident at once (one per CU: the phase kernels need
   // > 80 KB of LDS) and the 4x4x1 path applies; else a launch per phase.  MMT_NO_FUSED_DECODER=1 forces the latter.
   const int dev = cur_dev(), ncu = dev_ncu(dev);
   const bool m4 = RC == 4 && mfma4_fits(dec);
-  // All NC*H workgroups must be resident at once: one per CU by their LDS footprint, checked against the occupancy query
-  // (not the CU count alone).  A device whose one-launch decode has timed out before (mmt_decoder_status) is not trusted again.
-  bool fuse_phases = allow_fused && m4 && NC * H <= ncu && !dec_env().no_fused &&
-                     !g_dev[dev].fused_disabled.load(std::memory_order_relaxed);
-  if (fuse_phases) fuse_phases = fused_grid_fits(d > 128, NC * H, ncu, d);
+  // One-launch forms: all their workgroups must be resident at once (one per CU by their LDS footprint), checked against the
+  // occupancy query, not the CU count alone.  A device whose one-launch decode has timed out before (mmt_decoder_status) is not
+  // trusted again.  The weight-stationary pipeline is preferred; the fused kernel needs NC*H <= #CUs.
+  int one_launch = ONE_LAUNCH_NONE;
+  PipeGeom pg = {0, 0, 0, nullptr};
+  if (allow_fused != 0 && m4 && !dec_env().no_fused && !g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) {
+    if (d == 256 && dec->d_ff == 64 * H) pg = pipe_geom(L, H, NC, ncu);      // the geometry the pipeline kernel is compiled for
+    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d)) one_launch = ONE_LAUNCH_PIPE;
+    else if (allow_fused != 2 && NC * H <= ncu && one_launch_fits(false, d > 128, NC * H, ncu, d)) one_launch = ONE_LAUNCH_FUSED;
+  }
+  const bool fuse_phases = one_launch != ONE_LAUNCH_NONE;
+  pg.x0buf = x0buf;
 
   const float *src = memory;
   const int rows = B * T;
@@ -1599,6 +2285,11 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
     c.memkv = memkv;
     c.sync = sync;
     c.nsync = fuse_phases ? (NC + 1) * 32 : 0;
+    const bool pipe = one_launch == ONE_LAUNCH_PIPE;
+    c.fill[0] = reinterpret_cast<unsigned *>(part[0]);
+    c.nfill[0] = pipe ? (int)((size_t)NC * 16 * d * (2 * H + 2)) : 0;
+    c.fill[1] = reinterpret_cast<unsigned *>(x0buf);
+    c.nfill[1] = pipe ? NC * 4 * d : 0;
     for (int l = 0; l < L; ++l) c.ckv[l] = dec->layer[l].ckv;
     const size_t lds = (size_t)16 * (c.ldx + c.ldb) * sizeof(float);
     hipLaunchKernelGGL(mmt_dec_ckv_kernel, dim3((rows + 15) / 16, L), dim3(CNT), lds, st, c);
@@ -1617,6 +2308,7 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   a.FS16 = dec->d_ff / H / 16;
   a.map_dim = map_dim;
   a.has_map_fusion = (!tgt && dec->has_map_fusion) ? 1 : 0;
+  a.tagged = m4 ? 1 : 0;
   a.input_fc = dec->input_fc;
   a.output_fc = dec->output_fc;
   a.pe = dec->pe;
@@ -1641,12 +2333,12 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   const bool cpw2 = d > 128;
   if (m4) {
     // (CPW still sizes the K-split of the head's small linears, which stay on 16x16x4 tiles)
-    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, fuse_phases, st)
-                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, fuse_phases, st);
+    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st)
+                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st);
   }
   if (dh == 32)
-    return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st)
-                : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st);
-  return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st)
-              : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, false, st);
+    return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st)
+                : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st);
+  return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st)
+              : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st);
 }

@@ -491,11 +491,12 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T);
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                bool allow_fused, void *stream);
+                                int allow_fused, void *stream);
 
 static std::atomic<int> g_decoder_impl_atomic{MMT_DECODER_AUTO};     // process-wide tuning knob; each call reads it once
 extern "C" int mmt_decoder_select(int impl) {
-  if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_LAUNCHES)
+  if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_LAUNCHES &&
+      impl != MMT_DECODER_CLUSTER_FUSED && impl != MMT_DECODER_CLUSTER_PIPELINE)
     return fail(MMT_EINVAL, "mmt_decoder_select: unknown implementation %d", impl);
   g_decoder_impl_atomic.store(impl, std::memory_order_relaxed);
   return MMT_OK;
@@ -524,7 +525,9 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   if (dec->has_mem_fusion && (!mem_feat || mem_feat_dim <= 0)) return fail(MMT_EINVAL, "mmt_decoder_forward: memory fusion configured but no mem_feat");
   const int d = dec->d_model;
   const bool cluster_ok = mmt_cluster_decoder_supports(dec, map_dim, tgt == nullptr, T, ph);
-  if (g_decoder_impl == MMT_DECODER_CLUSTER && !cluster_ok)
+  const bool want_cluster = g_decoder_impl == MMT_DECODER_CLUSTER || g_decoder_impl == MMT_DECODER_CLUSTER_FUSED ||
+                            g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE;
+  if (want_cluster && !cluster_ok)
     return fail(MMT_EINVAL, "mmt_decoder_forward: the cluster decoder does not support this geometry (d=%d H=%d f=%d)", d,
                 dec->nhead, dec->d_ff);
   int small = max_mlp_width(dec->head);
@@ -545,7 +548,7 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   // AUTO: the cluster kernels win up to ~2.5 rounds of 16-agent clusters x nhead workgroups over the chip (measured on MI355X,
   // 8 heads: B = 1024: 4.7 vs 5.1 ms, B = 2048: 9.1 vs 6.1 ms); beyond that the persistent kernel's weight reuse is faster.
   bool use_cluster = cluster_ok && g_decoder_impl != MMT_DECODER_PERSISTENT;
-  if (use_cluster && g_decoder_impl != MMT_DECODER_CLUSTER) {
+  if (use_cluster && !want_cluster) {
     int dev = 0, ncu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -553,7 +556,9 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   }
   if (use_cluster)
     return mmt_cluster_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T,
-                                       ph, pred_st, h_out, workspace, g_decoder_impl != MMT_DECODER_CLUSTER_LAUNCHES, stream);
+                                       ph, pred_st, h_out, workspace,
+                                       g_decoder_impl == MMT_DECODER_CLUSTER_LAUNCHES ? 0 : g_decoder_impl == MMT_DECODER_CLUSTER_FUSED ? 1
+                                       : g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE ? 2 : 3, stream);
   // buf = [ region A | region B ], region B additionally split in two for the map-fusion ping-pong
   const int half = std::max((3 * d + 1) / 2, 2 * (small + MMT_PAD));
   const int halfr = (half + 15) & ~15;

@@ -488,7 +488,8 @@ def decoder_select(impl: str = "auto"):
     """Choose the kernel family behind ``decoder_forward``: "auto" | "persistent" | "cluster" | "cluster_launches"
     (include/mmt_amd.h)."""
     table = {"auto": _lib.MMT_DECODER_AUTO, "persistent": _lib.MMT_DECODER_PERSISTENT, "cluster": _lib.MMT_DECODER_CLUSTER,
-             "cluster_launches": _lib.MMT_DECODER_CLUSTER_LAUNCHES}
+             "cluster_launches": _lib.MMT_DECODER_CLUSTER_LAUNCHES, "cluster_fused": _lib.MMT_DECODER_CLUSTER_FUSED,
+             "cluster_pipeline": _lib.MMT_DECODER_CLUSTER_PIPELINE}
     if impl not in table:
         raise MmtError(f"decoder_select: unknown implementation {impl!r}")
     _lib.check(_lib.load().mmt_decoder_select(table[impl]), "mmt_decoder_select")

@@ -218,23 +218,27 @@ def test_fused_decoder_is_bit_identical_to_launch_per_phase():
                                                         with_lanes=(mode == "lane_cnn")), dev)
             ops.decoder_select("cluster_launches")
             want = model.predict(x, x_st, lanes, None, maps, 12)
-            ops.decoder_select("cluster")
-            for it in range(8):
-                if it % 2:
-                    with torch.cuda.stream(other):
-                        side.add_(1.0)                     # streams through the caches beside the decode
-                got = model.predict(x, x_st, lanes, None, maps, 12)
-                for w, g_ in zip(_flat(want), _flat(got)):
-                    assert torch.isfinite(g_).all()
-                    assert torch.equal(w, g_), (mode, B, it)
+            for form in ("cluster_pipeline", "cluster_fused"):     # the weight-stationary pipeline, the every-phase fused kernel
+                ops.decoder_select(form)
+                for it in range(8):
+                    if it % 2:
+                        with torch.cuda.stream(other):
+                            side.add_(1.0)                     # streams through the caches beside the decode
+                    got = model.predict(x, x_st, lanes, None, maps, 12)
+                    for w, g_ in zip(_flat(want), _flat(got)):
+                        assert torch.isfinite(g_).all(), (form, mode, B, it)
+                        assert torch.equal(w, g_), (form, mode, B, it)
             torch.cuda.synchronize()
+            ops.decoder_status()
 
 
-def test_fused_decoder_times_out_loudly():
-    """Fault injection: one workgroup of cluster 0 leaves the one-launch decoder early (mmt_debug_decoder_stall), so its siblings
-    can never complete their wait.  Every wait is bounded: the launch ends (0.2 s), the final head launch turns the WHOLE call's
-    outputs into NaN (never stale numbers) and raises the device's fault word; mmt_decoder_status reports it as MMT_ELAUNCH, clears
-    it and keeps the one-launch form off on this device, so the re-issued call (ops.checked does that) returns the right numbers."""
+@pytest.mark.parametrize("form", ["cluster_pipeline", "cluster_fused"])
+def test_fused_decoder_times_out_loudly(form):
+    """Fault injection: one workgroup leaves the one-launch decoder early (mmt_debug_decoder_stall), so the workgroups that
+    depend on it can never complete their wait.  Every wait is bounded: the launch ends (0.2 s), the final head launch turns the
+    WHOLE call's outputs into NaN (never stale numbers) and raises the device's fault word; mmt_decoder_status reports it as
+    MMT_ELAUNCH, clears it and keeps the one-launch forms off on this device, so the re-issued call (ops.checked does that)
+    returns the right numbers.  Both one-launch forms: the weight-stationary pipeline and the every-phase fused kernel."""
     import time
     from multimodal_transformer_amd import _lib, ops
     from multimodal_transformer_amd._lib import MmtError
@@ -244,7 +248,7 @@ def test_fused_decoder_times_out_loudly():
     model, reg = _model(hp, dev)
     apply_recipe(reg.model_dict, seed=0)
     x, x_st, *_ = _to(make_batch(64, 8, 12, seed=2), dev)
-    ops.decoder_select("cluster")
+    ops.decoder_select(form)
     want, _ = model.predict(x, x_st, None, None, None, 12)
     ops.decoder_status()                                  # clean so far
     try:
@@ -258,12 +262,12 @@ def test_fused_decoder_times_out_loudly():
         with pytest.raises(MmtError, match="gave up"):
             ops.decoder_status()
         ops.decoder_status()                              # reported once, then clear
-        # the one-launch form is now off on this device: the same call (stall still armed) runs launch-per-phase and is right
+        # the one-launch forms are now off on this device: the same call (stall still armed) runs launch-per-phase and is right
         again, _ = model.predict(x, x_st, None, None, None, 12)
         assert torch.equal(want, again)
         ops.decoder_status()
         # and the wrapper the callers use re-issues by itself
-        lib.mmt_debug_decoder_stall(0)                    # re-arms the one-launch form
+        lib.mmt_debug_decoder_stall(0)                    # re-arms the one-launch forms
         lib.mmt_debug_decoder_stall(1)
         with pytest.warns(RuntimeWarning, match="re-issuing"):
             healed, _ = ops.checked(lambda: model.predict(x, x_st, None, None, None, 12))
@@ -290,11 +294,13 @@ def test_teacher_forced_decoder_full_width_agrees_across_kernel_families():
         tgt = torch.cat([torch.zeros(B, 1, 2, device=dev), y_st[:, :-1]], dim=1).contiguous()
         dec = reg.model_dict["VEHICLE/decoder/transformer_decoder"]
         out = {}
-        for impl in ("cluster", "cluster_launches", "persistent"):
+        for impl in ("cluster", "cluster_pipeline", "cluster_fused", "cluster_launches", "persistent"):
             ops.decoder_select(impl)
             out[impl] = dec(tgt, memory, None, None, pad.bool())
         assert torch.isfinite(out["cluster"]).all()
         assert torch.equal(out["cluster"], out["cluster_launches"])
+        assert torch.equal(out["cluster_pipeline"], out["cluster_launches"])
+        assert torch.equal(out["cluster_fused"], out["cluster_launches"])
         assert rel_err(out["cluster"].cpu().numpy(), out["persistent"].cpu().numpy()) <= 1e-5
 
 
