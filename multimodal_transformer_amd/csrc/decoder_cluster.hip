@@ -50,7 +50,7 @@ extern "C" int mmt_debug_read_clprof(unsigned long long *host, size_t n) {
 #define PPR_WGS 256
 #define PPR_VISITS 192
 __device__ unsigned long long g_pprof[PPR_WGS][PPR_VISITS][16];
-#define PSTAMP(visit, k) do { if (thread_idx() == 0 && blockIdx.x < PPR_WGS && (visit) < PPR_VISITS) g_pprof[blockIdx.x][visit][k] = wall_clock64(); } while (0)
+#define PSTAMP(visit, k) do { const int v_ = ((visit) >> 12) * 16 + ((visit) & 4095); if (thread_idx() == 0 && blockIdx.x < PPR_WGS && ((visit) & 4095) < 16 && v_ < PPR_VISITS) g_pprof[blockIdx.x][v_][k] = wall_clock64(); } while (0)
 extern "C" int mmt_debug_read_pprof(unsigned long long *host, size_t n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pprof), sizeof(unsigned long long) * n);
 }
@@ -1379,15 +1379,17 @@ __device__ __forceinline__ void pipe_give_up(const PipeSync &ps, int phase, int 
   __hip_atomic_store(ps.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   *ps.abort = 1;
 }
-// One wave (row `row` of cluster's 4) fetches what the previous phase left for it - residual row and the H partial rows, or (x0)
-// the embedded token - and re-fetches until every word carries the expected tag.  The first two attempts take everything (in the
-// steady state the rows are there or land within a round trip); after that only one 16-byte piece per lane is polled, with
-// s_sleep, so that idle stages do not load the memory system.  Returns false when it gave up (wave-uniform).
+// A red wave (row `row` of the cluster's 4) fetches what the previous phase left for it - residual row and the H partial rows,
+// or (X0) the embedded token - and re-fetches until every word carries the expected tag.  The first attempt takes everything (in
+// the steady state the rows are there or land within a round trip); after a miss the wave probes ONE 64-byte piece (four lanes)
+// of the last partial row, with s_sleep, until it shows the tag - idle stages must not load the memory system - and then takes
+// everything again.  Returns false when it gave up (wave-uniform).
 template <bool X0>
 __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const float *x0buf, int cluster, unsigned tag, const PipeSync &ps) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
   const unsigned co = live ? (unsigned)q * 16u : OOB, gstride = 16u * a.d * 4u;
+  const unsigned probe = q < 4 ? (unsigned)q * 16u : OOB;
   const rsrc_t res = mk_rsrc(X0 ? x0buf + ((size_t)cluster * 4 + row) * a.d : a.xres_in + ((size_t)cluster * 16 + row) * a.d);
   const rsrc_t pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
   unsigned long long t0 = 0;
@@ -1403,24 +1405,27 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
       }
     }
     if (__all(ok)) return true;
-    if (tries > 64 && (tries & 63) == 0 && t0 && wall_clock64() - t0 > PIPE_WAIT_TICKS) {
-      if (q == 0) pipe_give_up(ps, a.prof_idx, cluster);
-      return false;
+    if (!t0) t0 = wall_clock64();
+    if (tries > 0) {                     // the probe matched but a row is still on its way: look again shortly
+      __builtin_amdgcn_s_sleep(1);
+      if ((tries & 63) == 0 && wall_clock64() - t0 > PIPE_WAIT_TICKS) {
+        if (q == 0) pipe_give_up(ps, a.prof_idx + 1000 * row, cluster);
+        return false;
+      }
+      continue;
     }
-#ifndef MMT_PIPE_FULL_POLLS
-#define MMT_PIPE_FULL_POLLS 2
-#endif
-    if (tries >= MMT_PIPE_FULL_POLLS - 1) {                    // thin polling: the last partial row (or the token row) only
-      if (!t0) t0 = wall_clock64();
-      for (unsigned n = 0;; ++n) {
-        __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
-        const f32x4 v = X0 ? bl4x<AUX_SC1>(res, co) : bl4x<AUX_SC1>(pp, co, (unsigned)(a.H - 1) * gstride);
-        if (__all(!live || tag_ok(v, tag))) break;
-        if ((n & 15u) == 15u &&
-            (__hip_atomic_load(ps.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > PIPE_WAIT_TICKS)) {
-          if (q == 0 && wall_clock64() - t0 > PIPE_WAIT_TICKS) pipe_give_up(ps, a.prof_idx + (X0 ? 100000 : 0) + 1000 * row, cluster);
-          else if (q == 0) *ps.abort = 1;
+    for (unsigned n = 0;; ++n) {         // thin polling
+      __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, (unsigned)(a.H - 1) * gstride);
+      if (__all(q >= 4 || tag_ok(v, tag))) break;
+      if ((n & 15u) == 15u) {
+        const bool late = wall_clock64() - t0 > PIPE_WAIT_TICKS;
+        if (late || __hip_atomic_load(ps.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (q == 0) {
+            if (late) pipe_give_up(ps, a.prof_idx + 1000 * row + (X0 ? 100000 : 0), cluster);
+            else *ps.abort = 1;          // another workgroup gave up: follow
+          }
           return false;
         }
       }
@@ -1651,7 +1656,7 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
         if (m + f.R < f.NC) nx_cluster = m + f.R;
         else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
       }
-      if (!pipe_phase<DH, PHASE, NH, D, FS>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 16 + li)) return;
+      if (!pipe_phase<DH, PHASE, NH, D, FS>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li)) return;
       kv_ready = nx_cluster >= 0;
     }
   }
@@ -1683,7 +1688,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
 #pragma clang loop unroll(disable)
     for (int m = replica + j * f.R; m < f.NC; m += f.R * f.NHW, ++li) {
       const int a0 = m * 4, na = min(4, a.B - a0);
-      PSTAMP(s * 16 + li, 0);
+      PSTAMP(s * 4096 + li, 0);
       Red4Regs R;
       const bool red_wave = s > 0 && wave_id() < 4;
       if (red_wave) {
@@ -1697,7 +1702,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
           *reinterpret_cast<f32x4 *>(S.xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (red_wave) (void)poll_rows<false>(R, a, f.x0buf, m, tag_of_phase(p - 1u), ps);
-      PSTAMP(s * 16 + li, 1);
+      PSTAMP(s * 4096 + li, 1);
       __syncthreads();
       if (*ps.abort) return;
       if (red_wave) reduce4_finish<AUX_SC1>(R, a, m, S.xs, ldx, false, false);
@@ -1708,15 +1713,15 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
           S.tok[r * LDTOK + c] = a.tgt ? a.tgt[((size_t)(a0 + r) * a.ph + s) * a.n_in + c] : a.start_pos[(size_t)(a0 + r) * a.n_in + c];
         }
       __syncthreads();
-      PSTAMP(s * 16 + li, 4);
+      PSTAMP(s * 4096 + li, 4);
       embed_token<false>(a, m, S.tok, S.xs, ldx, false);      // rows tagged s & 1
       __syncthreads();
-      PSTAMP(s * 16 + li, 5);
+      PSTAMP(s * 4096 + li, 5);
       if (wave_id() < 4 && lane_id() < (d >> 2))       // the embedded token, write-through, 16 bytes per lane
         bs4x<AUX_SC1>(mk_rsrc(f.x0buf + ((size_t)m * 4 + wave_id()) * d), (unsigned)lane_id() * 16u,
                       *reinterpret_cast<const f32x4 *>(S.xs + wave_id() * ldx + 4 * lane_id()));
       __syncthreads();                                  // xs is rewritten by the next visit
-      PSTAMP(s * 16 + li, 6);
+      PSTAMP(s * 4096 + li, 6);
     }
   }
 }
@@ -1730,7 +1735,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
   PipeSync ps;
   ps.tmo = (gu32 *)f.sync;
   ps.abort = S.abort;
-  if (thread_idx() == 0) *ps.abort = 0;
+  if (thread_idx() == 0) ps.abort[0] = 0, ps.abort[1] = 0;      // abort flag, wake word of the polling waves
   __syncthreads();
   if (rb < f.nlayers * per_layer) {
     const int layer = rb / per_layer, q = rb - layer * per_layer;
