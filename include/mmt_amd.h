@@ -247,6 +247,14 @@ size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, int T, int ph
 #define MMT_DECODER_CLUSTER_FUSED 4      /* CLUSTER, one-launch forms: only the fused kernel (every workgroup runs every phase)    */
 #define MMT_DECODER_CLUSTER_PIPELINE 5   /* CLUSTER, one-launch forms: only the weight-stationary pipeline (a workgroup = a stage) */
 int mmt_decoder_select(int impl);
+/* Which kernel family the calling thread's last mmt_decoder_forward actually ran (benchmarks label their lines with it). */
+#define MMT_PATH_NONE 0
+#define MMT_PATH_PERSISTENT 1          /* mmt_decoder_kernel                                                   */
+#define MMT_PATH_CLUSTER_LAUNCHES16 2  /* mmt_dec_phase_kernel per phase (8- / 16-agent clusters, 16x16x4 MFMA) */
+#define MMT_PATH_CLUSTER_LAUNCHES4 3   /* mmt_dec_phase4_kernel per phase (4-agent clusters, 4x4x1 MFMA)        */
+#define MMT_PATH_CLUSTER_FUSED 4       /* mmt_dec_fused4_kernel: every phase in one launch                      */
+#define MMT_PATH_CLUSTER_PIPELINE 5    /* mmt_dec_pipe4_kernel: weight-stationary pipeline, one launch          */
+int mmt_decoder_last_path(void);
 /* Synchronises `stream` and reports whether a one-launch decode issued on the current device gave up on a wait since the
  * last call: MMT_OK, or MMT_ELAUNCH (that decode's outputs are NaN; the fault is cleared and the one-launch form stays
  * disabled on this device, so re-issuing the call runs launch-per-phase).  Callers check it where they synchronise anyway

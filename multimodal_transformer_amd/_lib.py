@@ -130,6 +130,7 @@ SIGNATURES = {
     "mmt_decoder_forward_static": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
                                              C.c_int, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_decoder_status": (C.c_int, [C.c_void_p]),
+    "mmt_decoder_last_path": (C.c_int, []),
     "mmt_debug_decoder_stall": (C.c_int, [C.c_int]),
     "mmt_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mmt_pack_conv": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),

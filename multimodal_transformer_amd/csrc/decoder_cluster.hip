@@ -31,6 +31,7 @@
 #include <cstring>
 
 int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
+void mmt_note_decoder_path(int path);                // transformer.hip: what mmt_decoder_last_path() reports
 
 // Sticky per-device fault word: raised by the final head launch of a decode whose in-kernel hand-offs timed out (the outputs of
 // that call are NaN).  Read and cleared by mmt_decoder_status().
@@ -2256,6 +2257,8 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   }
   const bool fuse_phases = one_launch != ONE_LAUNCH_NONE;
   pg.x0buf = x0buf;
+  mmt_note_decoder_path(one_launch == ONE_LAUNCH_PIPE ? MMT_PATH_CLUSTER_PIPELINE : one_launch == ONE_LAUNCH_FUSED ? MMT_PATH_CLUSTER_FUSED
+                        : m4 ? MMT_PATH_CLUSTER_LAUNCHES4 : MMT_PATH_CLUSTER_LAUNCHES16);
 
   const float *src = memory;
   const int rows = B * T;

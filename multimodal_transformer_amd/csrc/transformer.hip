@@ -493,6 +493,9 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
                                 int allow_fused, void *stream);
 
+static thread_local int g_last_path = MMT_PATH_NONE;
+void mmt_note_decoder_path(int path) { g_last_path = path; }
+extern "C" int mmt_decoder_last_path(void) { return g_last_path; }
 static std::atomic<int> g_decoder_impl_atomic{MMT_DECODER_AUTO};     // process-wide tuning knob; each call reads it once
 extern "C" int mmt_decoder_select(int impl) {
   if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_PERSISTENT && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_LAUNCHES &&
@@ -559,6 +562,7 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
                                        ph, pred_st, h_out, workspace,
                                        g_decoder_impl == MMT_DECODER_CLUSTER_LAUNCHES ? 0 : g_decoder_impl == MMT_DECODER_CLUSTER_FUSED ? 1
                                        : g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE ? 2 : 3, stream);
+  mmt_note_decoder_path(MMT_PATH_PERSISTENT);
   // buf = [ region A | region B ], region B additionally split in two for the map-fusion ping-pong
   const int half = std::max((3 * d + 1) / 2, 2 * (small + MMT_PAD));
   const int halfr = (half + 15) & ~15;

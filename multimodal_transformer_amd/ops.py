@@ -495,6 +495,19 @@ def decoder_select(impl: str = "auto"):
     _lib.check(_lib.load().mmt_decoder_select(table[impl]), "mmt_decoder_select")
 
 
+DECODER_PATHS = {0: "none", 1: "mmt_decoder_kernel (persistent decoder, one launch)",
+                 2: "mmt_dec_phase_kernel per phase (16-row clusters) + mmt_dec_ckv_kernel",
+                 3: "mmt_dec_phase4_kernel per phase (4-agent clusters) + mmt_dec_ckv_kernel + mmt_dec_phase_kernel (final head)",
+                 4: "mmt_dec_fused4_kernel (every phase in one launch) + mmt_dec_ckv_kernel + mmt_dec_phase_kernel (final head)",
+                 5: "mmt_dec_pipe4_kernel (weight-stationary pipeline, one launch) + mmt_dec_ckv_kernel + mmt_dec_phase_kernel (final head)"}
+
+
+def decoder_last_path():
+    """Kernel family the last decoder_forward of this thread actually ran (code, description)."""
+    code = int(_lib.load().mmt_decoder_last_path())
+    return code, DECODER_PATHS.get(code, "?")
+
+
 def decoder_status(stream=None):
     """Synchronise and raise MmtError if a one-launch decode on the current device timed out since the last check (its outputs
     are NaN; the library then keeps that form disabled on the device, so re-issuing the call succeeds)."""

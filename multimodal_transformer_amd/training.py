@@ -835,6 +835,34 @@ class Trainer:
         self.use_graph = use_graph
         self._g_fb = self._g_opt = None
         self.steps_done = 0
+        self.time_allreduce = False          # bench: HIP events around the gradient all-reduce (allreduce_ms())
+        self._ar_events = []
+        if self.world > 1:
+            self._sync_replicas(dist)
+
+    def _sync_replicas(self, dist):
+        """Data-parallel replicas must start identical (torch DDP broadcasts at construction; so does this): parameters from rank 0
+        (AdamW moments start at zero on every rank), then a checksum over all ranks as the proof."""
+        flat = torch.cat([p.data.reshape(-1) for _, p in self.engine.named_params])
+        dist.broadcast(flat, src=0, group=self.pg)
+        off = 0
+        for _, p in self.engine.named_params:
+            n = p.numel()
+            p.data.copy_(flat[off:off + n].view_as(p.data))
+            off += n
+        chk = flat.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.pg)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.pg)
+        if float(lo) != float(hi):
+            raise RuntimeError("Trainer: parameters differ across data-parallel ranks after the broadcast")
+
+    def allreduce_ms(self):
+        """Mean duration of the gradient all-reduce over the steps taken with ``time_allreduce`` set (None: never ran)."""
+        if not self._ar_events:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._ar_events) / len(self._ar_events)
 
     def _fwd_bwd(self):
         self.engine.forward()
@@ -861,7 +889,8 @@ class Trainer:
             self._opt()
 
     def step(self, x_st, y_st, maps=None, lanes=None):
-        """One optimisation step on this rank's shard; returns the local loss as a 1-element device tensor."""
+        """One optimisation step on this rank's shard; returns THIS RANK's loss (its shard's mean, not the global mean) as a
+        1-element device tensor."""
         self.engine.set_batch(x_st, y_st, maps, lanes)
         if self.use_graph:
             if self._g_fb is None:
@@ -871,7 +900,14 @@ class Trainer:
             self._fwd_bwd()
         if self.world > 1 or self.always_reduce:
             import torch.distributed as dist
-            dist.all_reduce(self.engine.flat_grad, group=self.pg)      # one flat fp32 bucket
+            if self.time_allreduce and self.engine.flat_grad.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                dist.all_reduce(self.engine.flat_grad, group=self.pg)
+                ev[1].record()
+                self._ar_events.append(ev)
+            else:
+                dist.all_reduce(self.engine.flat_grad, group=self.pg)      # one flat fp32 bucket
         if self.use_graph:
             self._g_opt.replay()
         else:
