@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, torch_ops
 from .._lib import MmtError
 from ..nn_component import CNNMapEncoder, Encoder, Lane_Encoder, Mlp, Trajectory_Decoder, ViT
 from .model_utils import ModeKeys
@@ -152,8 +152,7 @@ class MultimodalGenerativeCVAE(object):
                                           prediction_horizon, keep_h=self.__dict__.get("_keep_class_input", False))
         fusion = self._m("fusion/hist_map") if map_feature is not None else None
         packed = dec.packed(head=head, map_fusion=fusion)
-        pred, _ = ops.decoder_forward(packed, memory, memory_key_padding_mask, start, prediction_horizon,
-                                      map_feat=map_feature)
+        pred = torch_ops.decoder_ar_fwd(packed, memory, memory_key_padding_mask, start, prediction_horizon, map_feat=map_feature)
         return pred, []
 
     def non_at_dec(self, memory, memory_mask, memory_key_padding_mask, labels_st, n_s_t0, lane_feature, map_feature,
@@ -238,11 +237,11 @@ class MultimodalGenerativeCVAE(object):
         hist, lane = self.at_dec(memory, None, pad, n0, enc_lane, enc_map, prediction_horizon)
         node_pos = node_pos.contiguous()
         if self.hyperparams["lane_cnn_encoding"]:
-            m0 = ops.finalize(lane[0], node_pos)[0]
-            outs = [m0 if (self.lane_dedup or i == 0) else ops.finalize(lane[i], node_pos)[0]
+            m0 = torch_ops.unstandardize(lane[0], node_pos)
+            outs = [m0 if (self.lane_dedup or i == 0) else torch_ops.unstandardize(lane[i], node_pos)
                     for i in range(len(lane))]
             return None, torch.stack(outs, dim=1)
-        return ops.finalize(hist, node_pos)[0], lane
+        return torch_ops.unstandardize(hist, node_pos), lane
 
     def _loss(self, inputs, inputs_st, inputs_lane, labels, labels_st, map, ph, metres, mode):
         memory, _, pad, n0, node_pos, enc_lane, enc_map = self.obtain_encoded_tensors(

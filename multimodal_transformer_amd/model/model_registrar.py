@@ -50,6 +50,36 @@ def install_reference_aliases():
         sys.modules["vit_pytorch.vit"] = vv
 
 
+def _allowed_checkpoint_globals():
+    """What a registrar checkpoint may reference besides tensors: torch.nn module classes, this package's module classes (also
+    under the reference's import paths, see install_reference_aliases) and the activation functions nn.Transformer* layers hold."""
+    import collections
+    import inspect
+
+    import torch.nn.functional as F
+
+    from ..nn_component import modules as m
+    allowed = {"collections.OrderedDict": collections.OrderedDict, "builtins.set": set,
+               "torch.nn.functional.relu": F.relu, "torch.nn.functional.gelu": F.gelu,
+               "torch.nn.functional.leaky_relu": F.leaky_relu}
+    for name in dir(torch.nn.modules):
+        sub = getattr(torch.nn.modules, name)
+        if inspect.ismodule(sub):
+            for cn, cls in vars(sub).items():
+                if inspect.isclass(cls) and issubclass(cls, nn.Module) and cls.__module__ == sub.__name__:
+                    allowed[f"{sub.__name__}.{cn}"] = cls
+    ours = [n for n, c in vars(m).items() if inspect.isclass(c) and issubclass(c, nn.Module) and c.__module__ == m.__name__]
+    layout = {"Transformer_model": ["Encoder", "Decoder", "Lane_Decoder", "Trajectory_Decoder", "PositionalEncoding"],
+              "MLP": ["Mlp"], "map_encoder": ["CNNMapEncoder"], "Lane_encoder": ["Lane_Encoder"]}
+    for n in ours:
+        allowed[f"{m.__name__}.{n}"] = getattr(m, n)
+    for sub, names in layout.items():
+        for n in names:
+            allowed[f"nn_component.{sub}.{n}"] = getattr(m, n)
+    allowed["vit_pytorch.vit.ViT"] = allowed["vit_pytorch.ViT"] = m.ViT
+    return allowed
+
+
 class ModelRegistrar(nn.Module):
     def __init__(self, model_dir, device):
         super().__init__()
@@ -83,12 +113,26 @@ class ModelRegistrar(nn.Module):
     def save_models(self, curr_iter):
         torch.save(self.model_dict, self._path(curr_iter))
 
-    def load_models(self, iter_num):
-        """Reads this package's own checkpoints and the reference's (pickled module objects; the file is
-        trusted input exactly as in the reference, which calls torch.load on it unguarded)."""
+    def load_models(self, iter_num, trusted=False):
+        """Reads this package's own checkpoints and the reference's (``torch.save`` of the ``nn.ModuleDict``: pickled module
+        objects, model_registrar.py:58-75).  The file is read with torch's restricted unpickler (``weights_only=True``) with
+        exactly the module classes such a checkpoint is made of allow-listed; a file that references anything else is refused
+        unless ``trusted=True`` (then, and only then, it is unpickled in full, like the reference does unguarded)."""
         install_reference_aliases()
+        path = self._path(iter_num)
+        allowed = _allowed_checkpoint_globals()
+        needed = torch.serialization.get_unsafe_globals_in_checkpoint(path)
+        extra = sorted(n for n in needed if n not in allowed)
         self.model_dict.clear()
-        self.model_dict = torch.load(self._path(iter_num), map_location=self.device, weights_only=False)
+        if not extra:
+            with torch.serialization.safe_globals([(allowed[n], n) for n in needed]):
+                self.model_dict = torch.load(path, map_location=self.device, weights_only=True)
+        elif trusted:
+            self.model_dict = torch.load(path, map_location=self.device, weights_only=False)
+        else:
+            from .._lib import MmtError
+            raise MmtError(f"{path} references objects a registrar checkpoint has no business holding: {extra}; "
+                           "pass trusted=True to unpickle it anyway (executes code from the file)")
 
     def to(self, device):
         for _, model in self.model_dict.items():

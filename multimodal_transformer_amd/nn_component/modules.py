@@ -14,7 +14,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, torch_ops
 from .._lib import MmtError
 
 
@@ -103,11 +103,10 @@ class Encoder(_PackedMixin, nn.Module):
         """src (B,T,ninp) with NaN padding.  The causal mask and the ``isnan(src)[:,:,1]`` key padding mask
         are what mgcvae.py:276-282 always passes; they are rebuilt inside the kernel, so the two mask
         arguments are accepted for signature compatibility and ignored."""
-        memory, _ = ops.encoder_forward(self.packed(), src.contiguous(), want_mask=False)
-        return memory
+        return torch_ops.encoder_fwd(self.packed(), src.contiguous())[0]
 
     def forward_with_mask(self, src):
-        return ops.encoder_forward(self.packed(), src.contiguous(), want_mask=True)
+        return torch_ops.encoder_fwd(self.packed(), src.contiguous())
 
 
 class Decoder(_PackedMixin, nn.Module):
@@ -256,7 +255,7 @@ class Trajectory_Decoder(Decoder):
             # the reference passes the lane feature already repeated over T (mgcvae.py:350-351): every row equal
             mem_feat = lane_feature[:, 0, :].contiguous()
         dec = self.packed(use_mix_fc=lane_feature is not None)
-        _, h = ops.decoder_forward(dec, memory.contiguous(), pad, tgt=tgt.contiguous(), mem_feat=mem_feat)
+        h = torch_ops.decoder_tf_fwd(dec, memory.contiguous(), pad, tgt.contiguous(), mem_feat)
         return h
 
 
@@ -346,11 +345,11 @@ class CNNMapEncoder(_PackedMixin, nn.Module):
 
     def forward(self, x, training=False):
         """x is the already rescaled ``map*2-1`` raster, as in the reference's call (mgcvae.py:289-290)."""
-        return ops.cnn_forward(self._pk(x), x.contiguous(), input_affine=False)
+        return torch_ops.cnn_map_fwd(self._pk(x), x.contiguous(), False)
 
     def forward_raw(self, maps):
         """maps in [0,1]; the ``*2-1`` rescale is fused into the first conv's loads (saves one pass over HBM)."""
-        return ops.cnn_forward(self._pk(maps), maps.contiguous(), input_affine=True)
+        return torch_ops.cnn_map_fwd(self._pk(maps), maps.contiguous(), True)
 
 
 class Lane_Encoder(_PackedMixin, nn.Module):
@@ -368,7 +367,7 @@ class Lane_Encoder(_PackedMixin, nn.Module):
         stride = getattr(self, "stride", None) or self.convs[0].stride[0]
         n_samples = x.shape[-1]
         packed = self._packed(lambda sd: ops.PackedLane(sd, stride, n_samples))
-        return ops.lane_forward(packed, x.contiguous())
+        return torch_ops.lane_enc_fwd(packed, x.contiguous())
 
 
 class ViT(_PackedMixin, nn.Module):
@@ -423,9 +422,9 @@ class ViT(_PackedMixin, nn.Module):
     def forward(self, img):
         """img is the already rescaled ``map*2-1`` raster, as in the reference's call (mgcvae.py:295-296)."""
         cfg = self._cfg()
-        return ops.vit_forward(self._packed(lambda sd: ops.PackedVit(sd, cfg)), img.contiguous(), input_affine=False)
+        return torch_ops.vit_map_fwd(self._packed(lambda sd: ops.PackedVit(sd, cfg)), img.contiguous(), False)
 
     def forward_raw(self, maps):
         """maps in [0,1]; ``*2-1`` is applied while the patches are gathered."""
         cfg = self._cfg()
-        return ops.vit_forward(self._packed(lambda sd: ops.PackedVit(sd, cfg)), maps.contiguous(), input_affine=True)
+        return torch_ops.vit_map_fwd(self._packed(lambda sd: ops.PackedVit(sd, cfg)), maps.contiguous(), True)
