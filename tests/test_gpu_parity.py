@@ -424,6 +424,34 @@ def test_large_batch_properties():
     assert rel_err(big[:128].cpu().numpy(), small.cpu().numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("mode", ["lane_cnn", "map_cnn"])
+def test_config5_shard_batch_1024(mode):
+    """BASELINE config 5's per-GPU shard (Lane_encoding_CNN, 8192 agents over 8 GPUs = 1024) and the map configuration at the same
+    batch: a 24-agent slice against the fp64 oracle, and every 128-agent slice against the same agents run as a batch of 128
+    (other kernel family there: 4-agent clusters in one launch instead of 16-agent clusters per phase) to 1e-4."""
+    dev = _dev()
+    hp = make_hyperparams(mode, history=8, horizon=12)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    B = 1024
+    batch = make_batch(B, 8, 12, seed=21, with_map=(mode == "map_cnn"), with_lanes=(mode == "lane_cnn"))
+    x, x_st, y, y_st, lanes, maps = _to(batch, dev)
+    h, lane = model.predict(x, x_st, lanes, None, maps, 12)
+    got = (lane if mode == "lane_cnn" else h)
+    assert torch.isfinite(got).all()
+    node = batch["x"][:, -1, 0:2]
+    node = node[:, None, None, :] if mode == "lane_cnn" else node[:, None, :]
+    want = _oracle_predict(hp, reg, batch, 12, 24)
+    assert rel_err((got[:24].cpu().numpy() - node[:24]) / 80.0, (want - node[:24]) / 80.0) <= TOL
+    g = got.cpu().numpy()
+    for i in range(0, B, 128):
+        sl = slice(i, i + 128)
+        hs, ls = model.predict(x[sl].contiguous(), x_st[sl].contiguous(), lanes[sl].contiguous() if lanes is not None else None, None,
+                               maps[sl].contiguous() if maps is not None else None, 12)
+        part = (ls if mode == "lane_cnn" else hs).cpu().numpy()
+        assert rel_err((g[sl] - node[sl]) / 80.0, (part - node[sl]) / 80.0) <= TOL, i
+
+
 def test_error_paths():
     from multimodal_transformer_amd._lib import MmtError
     dev = _dev()
