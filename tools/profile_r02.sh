@@ -1,0 +1,13 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): kernel trace + FETCH_SIZE / WRITE_SIZE passes of tools/decode_only.py (Basic, B=128, AUTO decoder),
+# outputs under gpurun_out/prof_r02/.  Each rocprofv3 pass is its own short run (counters never combined with traces).
+set -e
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_r02
+mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 90 rocprofv3 --pmc $c -d $OUT/pmc_$c -o p --output-format csv -- python3 tools/decode_only.py 128 auto 25 > $OUT/pmc_$c.log 2>&1
+done
+timeout -s KILL 90 rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 tools/decode_only.py 128 auto 100 > $OUT/kt.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o k --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs --no-scalings > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+echo profiled
