@@ -220,6 +220,16 @@ int mmt_pack_jobs(const mmt_pack_job *table_dev, int njobs, void *stream);
 int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory,
                         uint8_t *pad_mask, void *stream);
 
+/* The same with a workspace (mmt_encoder_workspace_floats floats, ZEROED ONCE by the caller before its first use and again
+ * after a call that mmt_decoder_status reported as timed out; never shared by calls that overlap in time).  With it, batches
+ * small enough that two workgroups per agent are all resident (2 * ceil(B/8)*8 <= #CUs) split every layer over two
+ * workgroups that exchange partial sums through the workspace (Transformer_model.py:45-59 is unchanged mathematically; the K
+ * range of the out-projection and linear2 is summed in two halves).  Other batches / geometries: as mmt_encoder_forward.
+ * workspace == NULL: mmt_encoder_forward.  No counterpart in the reference. */
+size_t mmt_encoder_workspace_floats(const mmt_encoder *enc, int B, int T);
+int mmt_encoder_forward_ws(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory,
+                           uint8_t *pad_mask, float *workspace, void *stream);
+
 /* ---- autoregressive decode  (mgcvae.py:375-449 at_dec, basic/map branch, KV-cached) -------------
  * memory (B,T,d); pad_mask (B,T) uint8 or NULL; start_pos (B,n_in) standardised; map_feat (B,m) or NULL;
  * mem_feat (B,mf) or NULL (lane feature repeated over T, mgcvae.py:404-407);

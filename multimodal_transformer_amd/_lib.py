@@ -123,6 +123,8 @@ SIGNATURES = {
     "mmt_lin4_second_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mmt_pack_lin4_second": (C.c_int, [fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_void_p]),
     "mmt_encoder_forward": (C.c_int, [C.POINTER(Encoder), fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_encoder_workspace_floats": (C.c_size_t, [C.POINTER(Encoder), C.c_int, C.c_int]),
+    "mmt_encoder_forward_ws": (C.c_int, [C.POINTER(Encoder), fptr, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
     "mmt_decoder_workspace_floats": (C.c_size_t, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     "mmt_decoder_select": (C.c_int, [C.c_int]),
     "mmt_decoder_forward": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,

@@ -2195,10 +2195,16 @@ static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d) {
   return per_cu >= 1 && grid <= per_cu * ncu;
 }
 
-// Reports (and clears) a timed-out one-launch decode on the current device; see include/mmt_amd.h.
+unsigned mmt_split_encoder_take_fault();      // encoder_split.hip
+
+// Reports (and clears) a timed-out one-launch decode / split encoder on the current device; see include/mmt_amd.h.
 extern "C" int mmt_decoder_status(void *stream) {
   hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_status: %s", hipGetErrorString(e));
+  if (mmt_split_encoder_take_fault())
+    return mmt_set_error(MMT_ELAUNCH, "mmt_encoder_forward_ws: a workgroup of the two-workgroups-per-agent encoder gave up waiting for "
+                                      "its partner (GPU shared or CU-masked?); that call's memory rows are NaN.  That form is now "
+                                      "disabled on this device: re-issue the call");
   unsigned v = 0;
   e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_decoder_fault), sizeof(v));
   if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_status: %s", hipGetErrorString(e));

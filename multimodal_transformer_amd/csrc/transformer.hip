@@ -444,13 +444,31 @@ static int check_tf(int d, int H, int f, int L, const char *who) {
   return MMT_OK;
 }
 
+// encoder_split.hip
+int mmt_encoder_forward_split(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory, uint8_t *pad_mask,
+                              float *workspace, void *stream);
+
+static int encoder_forward_impl(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory, uint8_t *pad_mask,
+                                float *workspace, void *stream);
 extern "C" int mmt_encoder_forward(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory,
                                    uint8_t *pad_mask, void *stream) {
+  return encoder_forward_impl(enc, x_st, B, T, memory, pad_mask, nullptr, stream);
+}
+extern "C" int mmt_encoder_forward_ws(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory,
+                                      uint8_t *pad_mask, float *workspace, void *stream) {
+  return encoder_forward_impl(enc, x_st, B, T, memory, pad_mask, workspace, stream);
+}
+static int encoder_forward_impl(const mmt_encoder *enc, const float *x_st, int B, int T, float *memory, uint8_t *pad_mask,
+                                float *workspace, void *stream) {
   if (!enc || !x_st || !memory) return fail(MMT_EINVAL, "mmt_encoder_forward: null pointer");
   if (B <= 0) return fail(MMT_EINVAL, "mmt_encoder_forward: empty batch (B=%d)", B);
   if (T <= 0 || T > 32) return fail(MMT_EINVAL, "mmt_encoder_forward: history length T=%d outside 1..32", T);
   if (int rc = check_tf(enc->d_model, enc->nhead, enc->d_ff, enc->nlayers, "mmt_encoder_forward")) return rc;
   if (enc->n_in <= 0 || enc->n_in > 64) return fail(MMT_EINVAL, "mmt_encoder_forward: n_in=%d", enc->n_in);
+  if (workspace) {      // small batches: two workgroups per agent tile (encoder_split.hip); 0 = not this time
+    const int rc = mmt_encoder_forward_split(enc, x_st, B, T, memory, pad_mask, workspace, stream);
+    if (rc != 0) return rc < 0 ? rc : MMT_OK;
+  }
   const int d = enc->d_model;
   const int wide = std::max(std::max(3 * d, (enc->d_ff + 15) & ~15), (enc->n_in + 15) & ~15);
   EncLaunch P;

@@ -479,8 +479,9 @@ def encoder_forward(enc: PackedEncoder, x_st: torch.Tensor, want_mask: bool = Tr
     memory = torch.empty(B, T, enc.d_model, dtype=torch.float32, device=x_st.device)
     pad = torch.empty(B, T, dtype=torch.uint8, device=x_st.device) if want_mask else None
     lib = _lib.load()
-    _lib.check(lib.mmt_encoder_forward(C.byref(enc.desc), _ptr(x_st), B, T, _ptr(memory), _ptr(pad), _stream()),
-               "mmt_encoder_forward")
+    ws = _encoder_workspace(lib.mmt_encoder_workspace_floats(C.byref(enc.desc), B, T), x_st.device) if B <= 256 else None
+    _lib.check(lib.mmt_encoder_forward_ws(C.byref(enc.desc), _ptr(x_st), B, T, _ptr(memory), _ptr(pad), _ptr(ws), _stream()),
+               "mmt_encoder_forward_ws")
     return memory, pad
 
 
@@ -511,7 +512,11 @@ def decoder_last_path():
 def decoder_status(stream=None):
     """Synchronise and raise MmtError if a one-launch decode on the current device timed out since the last check (its outputs
     are NaN; the library then keeps that form disabled on the device, so re-issuing the call succeeds)."""
-    _lib.check(_lib.load().mmt_decoder_status(_stream() if stream is None else stream), "mmt_decoder_status")
+    try:
+        _lib.check(_lib.load().mmt_decoder_status(_stream() if stream is None else stream), "mmt_decoder_status")
+    except MmtError:
+        _enc_ws_cache.clear()      # (a timed-out split encoder leaves its progress words inconsistent: fresh, zeroed buffers next time)
+        raise
 
 
 def checked(fn):
@@ -538,6 +543,20 @@ def _workspace(nfloats, device):
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(int(nfloats * 1.25) + 1024, dtype=torch.float32, device=device)
         _ws_cache[key] = buf
+    return buf
+
+
+_enc_ws_cache = {}
+
+
+def _encoder_workspace(nfloats, device):
+    """Exchange buffers + progress words of the two-workgroups-per-agent encoder: ZEROED when allocated (the kernel keeps the words
+    consistent from call to call), one per (device, stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    buf = _enc_ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.zeros(int(nfloats) + 1024, dtype=torch.float32, device=device)
+        _enc_ws_cache[key] = buf
     return buf
 
 
