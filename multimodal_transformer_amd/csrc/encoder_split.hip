@@ -41,17 +41,18 @@ constexpr unsigned long long ENC_WAIT_TICKS = 20000000ull;     // 0.2 s of the 1
 // real slab (v / grp) * stride + base + v % grp; chunks [c_off, c_off + K16) of the K16full the rows are laid out with
 struct LinG {
   const float *w;
-  int K16, K16full, c_off, N16, grp, stride, base;
+  int K16, K16full, c_off, N16, grp, stride, base, v0;      // v0: first virtual slab of this call (a linear may be run in two calls)
   __device__ __forceinline__ int slab(int v) const {
-    v = min(v, N16 - 1);                              // a dead slab re-reads the last one (in bounds, discarded)
+    v = max(min(v, N16 - 1), 0) + v0;                 // a dead slab re-reads the last one (in bounds, discarded)
     return (v / grp) * stride + base + v % grp;
   }
 };
-__device__ __forceinline__ LinG no_lin() { return LinG{nullptr, 0, 0, 0, 0, 1, 0, 0}; }
+__device__ __forceinline__ LinG no_lin() { return LinG{nullptr, 0, 0, 0, 0, 1, 0, 0, 0}; }
 
+template <int SL = WSL>
 __device__ __forceinline__ void wload_g(WRegs &r, const f32x4 *W4, const LinG &G, int s0, int c0) {
 #pragma unroll
-  for (int s = 0; s < WSL; ++s) {
+  for (int s = 0; s < SL; ++s) {
     const f32x4 *p = W4 + ((size_t)G.slab(s0 + s) * G.K16full + G.c_off + c0) * 64;
 #pragma unroll
     for (int u = 0; u < WU; ++u) r.w[s][u] = p[(size_t)u * 64];
@@ -60,22 +61,23 @@ __device__ __forceinline__ void wload_g(WRegs &r, const f32x4 *W4, const LinG &G
 
 // tile_linear (mmt_device.cuh) for one 16-row tile with a slab / chunk selection; K16 must be a multiple of WU.
 // X columns are REAL k positions (the chunk offset applies to X too); epilogue columns are REAL output columns.
-template <bool PRE, class Epi>
+// SL slabs per wave per set (the linear that follows is prefetched with its own NSL).
+template <bool PRE, int SL, int NSL, class Epi>
 __device__ __forceinline__ void tile_linear_g(const float *__restrict__ X, int ldx, const LinG G, Epi epi, WRegs &pre, const LinG next) {
-  const int lane = lane_id(), nw = n_waves(), first = wave_id() * WSL;
+  const int lane = lane_id(), nw = n_waves(), first = wave_id() * SL;
   const float *xrow = X + (lane & 15) * ldx + (lane >> 4) * 4 + G.c_off * 16;
   const f32x4 *W4 = reinterpret_cast<const f32x4 *>(G.w) + lane;
   const f32x4 *N4 = reinterpret_cast<const f32x4 *>(next.w) + lane;
   const bool do_next = next.w != nullptr;
-  f32x4 acc[WSL];
+  f32x4 acc[SL];
 #pragma unroll
-  for (int s = 0; s < WSL; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  typename Epi::template Pre<1> pb[WSL];
-  const int nsets = first < G.N16 ? (G.N16 - first + nw * WSL - 1) / (nw * WSL) : 0;
+  for (int s = 0; s < SL; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  typename Epi::template Pre<1> pb[SL];
+  const int nsets = first < G.N16 ? (G.N16 - first + nw * SL - 1) / (nw * SL) : 0;
   const int gps = G.K16 / WU, total = nsets * gps;
   WRegs cur;
   if (PRE) cur = pre;
-  else if (total > 0) wload_g(cur, W4, G, first, 0);
+  else if (total > 0) wload_g<SL>(cur, W4, G, first, 0);
   int set = 0, kg = 0;
   for (int g = 0; g < total; ++g) {
     int kg1 = kg + 1, set1 = set;
@@ -84,12 +86,12 @@ __device__ __forceinline__ void tile_linear_g(const float *__restrict__ X, int l
       ++set1;
     }
     WRegs nxt = cur;
-    if (g + 1 < total) wload_g(nxt, W4, G, first + set1 * nw * WSL, kg1 * WU);
-    else if (do_next) wload_g(nxt, N4, next, first, 0);
-    const int s0 = first + set * nw * WSL;
+    if (g + 1 < total) wload_g<SL>(nxt, W4, G, first + set1 * nw * SL, kg1 * WU);
+    else if (do_next) wload_g<NSL>(nxt, N4, next, wave_id() * NSL, 0);
+    const int s0 = first + set * nw * SL;
     if (kg == gps - 1) {
 #pragma unroll
-      for (int s = 0; s < WSL; ++s) epi.prep(pb[s], (lane >> 4) * 4, G.slab(s0 + s) * 16 + (lane & 15));
+      for (int s = 0; s < SL; ++s) epi.prep(pb[s], (lane >> 4) * 4, G.slab(s0 + s) * 16 + (lane & 15));
     }
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
@@ -97,11 +99,11 @@ __device__ __forceinline__ void tile_linear_g(const float *__restrict__ X, int l
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int s = 0; s < WSL; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], cur.w[s][u][e], acc[s], 0, 0, 0);
+        for (int s = 0; s < SL; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], cur.w[s][u][e], acc[s], 0, 0, 0);
     }
     if (kg == gps - 1) {
 #pragma unroll
-      for (int s = 0; s < WSL; ++s) {
+      for (int s = 0; s < SL; ++s) {
         if (s0 + s < G.N16) {
           const int col = G.slab(s0 + s) * 16 + (lane & 15);
 #pragma unroll
@@ -114,7 +116,7 @@ __device__ __forceinline__ void tile_linear_g(const float *__restrict__ X, int l
     kg = kg1;
     set = set1;
   }
-  if (total == 0 && do_next) wload_g(cur, N4, next, first, 0);
+  if (total == 0 && do_next) wload_g<NSL>(cur, N4, next, wave_id() * NSL, 0);
   pre = cur;
 }
 
@@ -181,22 +183,57 @@ __device__ __forceinline__ bool await(Xchg &X) {
   return *X.abort == 0;
 }
 
-// xs = LayerNorm(xs + bias + p0 + p1): p(mine) from the LDS tile, p(partner) from its slot (sc1 loads); the two partials are added
-// in the order of the halves, so both workgroups of a tile hold the same bits
+// xs = LayerNorm(xs + bias + p0 + p1) in ONE pass: 32 lanes per row (16 rows = the 512 threads), two float4 column groups per
+// lane (d <= 256); p(mine) from the LDS tile, p(partner) from its slot (sc1 loads).  The two partials are added in the order of
+// the halves and the row statistics are reduced in a fixed order, so both workgroups of a tile hold the same bits.
 __device__ __forceinline__ void combine_norm(Xchg &X, int half, float *xs, int ldx, const float *pb, int ldp, const float *bias,
                                              const mmt_norm &N, int nrows, int d) {
   const float *src = X.in[X.e & 1];
-  const int nq = d >> 2;
-  for (int i = threadIdx.x; i < nrows * nq; i += ENT) {
-    const int r = i / nq, q = i - r * nq;
-    const f32x4 theirs = bl4x<AUX_SC1>(mk_rsrc(src + (size_t)r * d), (unsigned)q * 16u);
-    const f32x4 mine = *reinterpret_cast<const f32x4 *>(pb + r * ldp + 4 * q);
-    const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 4 * q);
-    f32x4 *x = reinterpret_cast<f32x4 *>(xs + r * ldx + 4 * q);
-    *x = (*x + b) + ((half == 0 ? mine : theirs) + (half == 0 ? theirs : mine));
+  const int nq = d >> 2, row = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+  const bool live = row < nrows;
+  f32x4 v[2];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = l32 + 32 * j;
+    const bool ok = live && q < nq;
+    const f32x4 theirs = bl4x<AUX_SC1>(mk_rsrc(src + (size_t)row * d), ok ? (unsigned)q * 16u : OOB);
+    v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const f32x4 mine = *reinterpret_cast<const f32x4 *>(pb + row * ldp + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 4 * q);
+      const f32x4 x = *reinterpret_cast<const f32x4 *>(xs + row * ldx + 4 * q);
+      v[j] = (x + b) + ((half == 0 ? mine : theirs) + (half == 0 ? theirs : mine));
+    }
+    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
   }
-  __syncthreads();
-  layer_norm_rows<false>(xs, ldx, nrows, d, N);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  const float mu = s / (float)d;
+  float var = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (l32 + 32 * j < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dl = v[j][e] - mu;
+        var += dl * dl;
+      }
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 32);
+  const float rstd = 1.0f / sqrtf(var / (float)d + MMT_LN_EPS);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = l32 + 32 * j;
+    if (live && q < nq) {
+      const f32x4 g = *reinterpret_cast<const f32x4 *>(N.g + 4 * q), be = *reinterpret_cast<const f32x4 *>(N.b + 4 * q);
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mu) * rstd * g[e] + be[e];
+      *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = y;
+    }
+  }
   __syncthreads();
   ++X.e;
 }
@@ -252,18 +289,22 @@ __global__ __launch_bounds__(ENT) void mmt_encoder_split_kernel(mmt_encoder E, S
   }
   __syncthreads();
   const int D16 = d >> 4, F16 = f >> 4, hh = H / 2, hs16 = hh * DH / 16;      // hs16: slabs of one of q / k / v for my heads
-  const LinG gIn{E.input_fc.w, round16(E.n_in) >> 4, round16(E.n_in) >> 4, 0, D16, D16, 0, 0};
-  auto gQKV = [&](int L) { return LinG{E.layer[L].qkv.w, D16, D16, 0, 3 * hs16, hs16, D16, half * hs16}; };
-  auto gOut = [&](int L) { return LinG{E.layer[L].out.w, hs16, D16, half * hs16, D16, D16, 0, 0}; };
-  auto gFf1 = [&](int L) { return LinG{E.layer[L].ff1.w, D16, D16, 0, F16 / 2, F16 / 2, 0, half * (F16 / 2)}; };
-  auto gFf2 = [&](int L) { return LinG{E.layer[L].ff2.w, F16 / 2, F16, half * (F16 / 2), D16, D16, 0, 0}; };
+  const LinG gIn{E.input_fc.w, round16(E.n_in) >> 4, round16(E.n_in) >> 4, 0, D16, D16, 0, 0, 0};
+  // q|k|v of my heads = 3 * hs16 slabs; run as a body of whole 2-slabs-per-wave sets and a tail at 1 slab per wave (24 slabs on
+  // 8 waves: 16 + 8 instead of two sets of 16 of which the second is half empty)
+  const int nw = ENT / 64, qkv_n = 3 * hs16, qkv_body = (qkv_n / (2 * nw)) * (2 * nw), qkv_tail = qkv_n - qkv_body;
+  auto gQKV = [&](int L) { return LinG{E.layer[L].qkv.w, D16, D16, 0, qkv_body, hs16, D16, half * hs16, 0}; };
+  auto gQKVt = [&](int L) { return LinG{E.layer[L].qkv.w, D16, D16, 0, qkv_tail, hs16, D16, half * hs16, qkv_body}; };
+  auto gOut = [&](int L) { return LinG{E.layer[L].out.w, hs16, D16, half * hs16, D16, D16, 0, 0, 0}; };
+  auto gFf1 = [&](int L) { return LinG{E.layer[L].ff1.w, D16, D16, 0, F16 / 2, F16 / 2, 0, half * (F16 / 2), 0}; };
+  auto gFf2 = [&](int L) { return LinG{E.layer[L].ff2.w, F16 / 2, F16, half * (F16 / 2), D16, D16, 0, 0, 0}; };
   WRegs pre;
   {
     // input_fc has K16 = 1 < WU: plain loop (tile_linear's small-K path), both workgroups compute all of it
     InEpi epi{E.input_fc.b, E.pe, xs, d, T, ldx};
     WRegs scratch;
     tile_linear<1, false>(buf, ldb, E.input_fc.w, gIn.K16, D16, epi, scratch, no_next());
-    wload_g(pre, reinterpret_cast<const f32x4 *>(E.layer[0].qkv.w) + lane_id(), gQKV(0), wave_id() * WSL, 0);
+    wload_g<2>(pre, reinterpret_cast<const f32x4 *>(E.layer[0].qkv.w) + lane_id(), gQKV(0), wave_id() * 2, 0);
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)DH);
@@ -272,7 +313,8 @@ __global__ __launch_bounds__(ENT) void mmt_encoder_split_kernel(mmt_encoder E, S
     const mmt_enc_layer &W = E.layer[L];
     {
       LdsEpi<EPI_STORE> epi{W.qkv.b, buf, 3 * d, ldb};
-      tile_linear_g<true>(xs, ldx, gQKV(L), epi, pre, gOut(L));
+      tile_linear_g<true, 2, 1>(xs, ldx, gQKV(L), epi, pre, gQKVt(L));
+      tile_linear_g<true, 1, 2>(xs, ldx, gQKVt(L), epi, pre, gOut(L));
     }
     __syncthreads();
     for (int g = tid >> 4; g < nrows * hh; g += ENT >> 4) {
@@ -284,7 +326,7 @@ __global__ __launch_bounds__(ENT) void mmt_encoder_split_kernel(mmt_encoder E, S
     __syncthreads();
     {
       LdsEpi<EPI_STORE> epi{nullptr, pb, d, ldx};
-      tile_linear_g<true>(buf, ldb, gOut(L), epi, pre, gFf1(L));
+      tile_linear_g<true, 2, 2>(buf, ldb, gOut(L), epi, pre, gFf1(L));
     }
     __syncthreads();
     publish(X, pb, ldx, nrows, d);
@@ -293,12 +335,12 @@ __global__ __launch_bounds__(ENT) void mmt_encoder_split_kernel(mmt_encoder E, S
     combine_norm(X, half, xs, ldx, pb, ldx, W.out.b, W.ln1, nrows, d);
     {
       LdsEpi<EPI_RELU> epi{W.ff1.b, buf, f, ldb};
-      tile_linear_g<true>(xs, ldx, gFf1(L), epi, pre, gFf2(L));
+      tile_linear_g<true, 2, 2>(xs, ldx, gFf1(L), epi, pre, gFf2(L));
     }
     __syncthreads();
     {
       LdsEpi<EPI_STORE> epi{nullptr, pb, d, ldx};
-      tile_linear_g<true>(buf, ldb, gFf2(L), epi, pre, L + 1 < E.nlayers ? gQKV(L + 1) : no_lin());
+      tile_linear_g<true, 2, 2>(buf, ldb, gFf2(L), epi, pre, L + 1 < E.nlayers ? gQKV(L + 1) : no_lin());
     }
     __syncthreads();
     publish(X, pb, ldx, nrows, d);
