@@ -233,16 +233,21 @@ def timed(group, fn, steps, warmup):
     return group.max(time.perf_counter() - t0), out
 
 
-def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, group, with_map=False, with_lanes=False):
+def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, group, with_map=False, with_lanes=False,
+                dropout=False):
     """BASELINE config 2: Basic transformer training step (fwd + bwd + clip + AdamW), data-parallel with one flat
-    RCCL gradient all-reduce per step, 128 agents per GPU (global batch 128 * world)."""
+    RCCL gradient all-reduce per step, 128 agents per GPU (global batch 128 * world).  ``dropout`` False: the dropout-free graph
+    (what training parity and the CPU baseline are defined on); True: the modules' own probabilities (0.2 Transformer / PE, 0.5
+    map feature, 0.1 ViT), masks drawn in-graph every step."""
     from multimodal_transformer_amd.training import Trainer
     hp["autoregressive"] = True
     batches = [make_batch(B, history, ph, seed=100 + 10 * rank + i, with_map=with_map, with_lanes=with_lanes) for i in range(4)]
     dev_batches = [(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev),
                     torch.from_numpy(b["map"]).to(dev) if with_map else None,
                     torch.from_numpy(b["lanes"]).to(dev) if with_lanes else None) for b in batches]
-    tr = Trainer(model, B, history + 1, ph, use_graph=True)
+    tr = Trainer(model, B, history + 1, ph, use_graph=True, dropout=None if dropout else False, seed=1234)
+    if dropout and not tr.engine.drop.active:
+        raise RuntimeError("bench_train: dropout requested but the modules carry no dropout probability")
     it = [0]
 
     def step():
@@ -261,7 +266,10 @@ def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, grou
             "allreduce_ms": tr.allreduce_ms(), "allreduce_bytes": 4 * n_par if world > 1 else 0,
             "parallelism": f"dp{world}, one flat fp32 all-reduce of {n_par} gradients per step (RCCL), parameters broadcast from "
                            f"rank 0 at start" if world > 1 else "single GPU",
-            "dropout": 0.0, "last_loss_rank0": float(loss),
+            "dropout": ({"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
+                         "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
+                         "decode": "step by step on the stash kernels (tokens depend on the masks)"} if dropout else 0.0),
+            "last_loss_rank0": float(loss),
             "algorithmic_tflops": 3 * (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * world * steps / elapsed / 1e12}
 
 
@@ -408,6 +416,14 @@ def main():
                                 with_lanes=(args.mode == "lane_cnn"))
         except Exception as e:
             train = {"error": f"{type(e).__name__}: {e}"}
+        if train is not None and "error" not in train:
+            try:        # the same step as the reference trains it: dropout on
+                td = bench_train(model, hp, dev, B, args.history, ph, rank, world, max(5, args.train_steps // 2), 3, group,
+                                 with_map=(args.mode in ("map_cnn", "map_vit")), with_lanes=(args.mode == "lane_cnn"), dropout=True)
+                train["with_dropout"] = {k: td[k] for k in ("value", "unit", "ms_per_step", "steps", "dropout", "allreduce_ms",
+                                                            "last_loss_rank0")}
+            except Exception as e:
+                train["with_dropout"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         x, x_st, lanes, maps = tensors

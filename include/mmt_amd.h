@@ -162,6 +162,23 @@ typedef struct {
   int32_t splitk, pad_;
   int64_t part_stride;
   float *asum;
+  /* dropout (training; nn.Dropout / F.dropout, Transformer_model.py:28-30,77-79,126-129): `drop` holds one keep byte per
+   * output (0 = dropped, row stride ld_drop bytes, written by mmt_dropout_mask); kept values are multiplied by drop_scale =
+   * 1/(1-p).  With v = acc + bias:  drop_after_add ? keep*(v + addend) : keep*[relu](v) + addend.   drop == NULL: no dropout.
+   * mask_scale != 0: outputs that pass `mask` are also multiplied by it (backward of relu followed by dropout). */
+  const uint8_t *drop;
+  int64_t ld_drop;
+  float drop_scale;
+  int32_t drop_after_add;
+  float mask_scale;
+  int32_t pad2_;
+  /* with ln_xhat: the multiplied operand is keep*A' (the gradient entering the dropped sub-layer), also written to ln_dxm
+   * (row stride ld_ln) for the deferred weight gradients; ln_dx still receives A' (the residual path).  NULL: none. */
+  const uint8_t *ln_drop;
+  int64_t ld_ln_drop;
+  float *ln_dxm;
+  float ln_drop_scale;
+  int32_t pad3_;
 } mmt_gemm_args;
 
 /* short-sequence multi-head attention with explicit (batch stride, row stride) per operand, in floats */
@@ -173,6 +190,11 @@ typedef struct {
   int64_t p_hs, p_rs;               /* probs strides; contiguous (B,H,Lq,Lk) is p_hs = Lq*Lk, p_rs = Lk */
   int32_t B, H, Lq, Lk, dh, causal, causal_offset;
   float scale;
+  /* dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) in training): keep bytes addressed like
+   * `probs`; o = (keep*probs) v, the stash keeps the undropped probabilities.  NULL: none. */
+  const uint8_t *pdrop;
+  float pdrop_scale;
+  int32_t pad_;
 } mmt_attn_args;
 
 typedef struct {
@@ -337,8 +359,20 @@ int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, 
 /* y = [relu](LayerNorm(x + res)) with eps 1e-5; stashes xhat (M,N), rstd (M)   (nn.LayerNorm; MLP.py:13-16) */
 int mmt_layernorm_fwd(const float *x, const float *res, int M, int N, const float *g, const float *b, int relu,
                       float *y, float *xhat, float *rstd, void *stream);
+/* drop != NULL (keep bytes (M,N), not with accumulate): dx_dropped = keep * drop_scale * dx, the gradient entering a
+ * sub-layer whose output went through dropout before the residual add */
 int mmt_layernorm_bwd(const float *dy, const float *xhat, const float *rstd, const float *g, const float *y_relu,
-                      int M, int N, float *dx, int accumulate, float *dy_masked, void *stream);
+                      int M, int N, float *dx, int accumulate, float *dy_masked, const uint8_t *drop, float drop_scale,
+                      float *dx_dropped, void *stream);
+/* ---- dropout for the training step (no counterpart call in the reference: torch draws its masks from the global generator;
+ * here every mask of a step is generated up front from a counter-based generator so that the forward stash pass and the
+ * backward see the same bits).  keep[i] = Philox4x32-10(key = rng_state[0], counter = (i/4, stream_id, rng_state[1]))[i%4]
+ * >= p*2^32 for i < n (n a multiple of 4, keep 4-byte aligned); rng_state = {seed, step} lives on the device so that a
+ * captured graph draws fresh masks on every replay: mmt_rng_advance adds 1 to the step. */
+int mmt_dropout_mask(uint8_t *keep, long n, float p, const uint64_t *rng_state, uint32_t stream_id, void *stream);
+int mmt_rng_advance(uint64_t *rng_state, void *stream);
+/* y = keep ? x*scale : 0 (y may alias x): F.dropout(encoded_map, 0.5) (mgcvae.py:291-293) and the ViT's dropouts */
+int mmt_dropout_apply(const float *x, const uint8_t *keep, float scale, float *y, long n, void *stream);
 int mmt_attention_fwd(const mmt_attn_args *a, void *stream);
 /* dq (=), dk += , dv += ; dk/dv share strides (dk_bs, dk_rs) */
 int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long do_bs, long do_rs, float *dq, long dq_bs,

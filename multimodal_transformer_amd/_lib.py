@@ -88,13 +88,17 @@ class GemmArgs(C.Structure):
                 ("K", C.c_int32), ("bias", fptr), ("addend", fptr), ("ld_add", C.c_int64), ("mask", fptr),
                 ("ld_mask", C.c_int64), ("relu", C.c_int32), ("accumulate", C.c_int32), ("ln_xhat", fptr),
                 ("ln_rstd", fptr), ("ln_g", fptr), ("ln_dx", fptr), ("ld_ln", C.c_int64), ("splitk", C.c_int32),
-                ("pad_", C.c_int32), ("part_stride", C.c_int64), ("asum", fptr)]
+                ("pad_", C.c_int32), ("part_stride", C.c_int64), ("asum", fptr),
+                ("drop", fptr), ("ld_drop", C.c_int64), ("drop_scale", C.c_float), ("drop_after_add", C.c_int32),
+                ("mask_scale", C.c_float), ("pad2_", C.c_int32), ("ln_drop", fptr), ("ld_ln_drop", C.c_int64),
+                ("ln_dxm", fptr), ("ln_drop_scale", C.c_float), ("pad3_", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("q", fptr), ("k", fptr), ("v", fptr), ("o", fptr), ("probs", fptr), ("pad", fptr)] + \
                [(n, C.c_int64) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs", "p_hs", "p_rs")] + \
-               [(n, C.c_int32) for n in ("B", "H", "Lq", "Lk", "dh", "causal", "causal_offset")] + [("scale", C.c_float)]
+               [(n, C.c_int32) for n in ("B", "H", "Lq", "Lk", "dh", "causal", "causal_offset")] + [("scale", C.c_float)] + \
+               [("pdrop", fptr), ("pdrop_scale", C.c_float), ("pad_", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -150,7 +154,11 @@ SIGNATURES = {
     "mmt_ln_param_grads": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_long, fptr, fptr, C.c_int, C.c_long, C.c_void_p]),
     "mmt_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, fptr, C.c_int, C.c_void_p]),
     "mmt_layernorm_fwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_int, fptr, fptr, fptr, C.c_void_p]),
-    "mmt_layernorm_bwd": (C.c_int, [fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, C.c_void_p]),
+    "mmt_layernorm_bwd": (C.c_int, [fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr, C.c_float, fptr,
+                                    C.c_void_p]),
+    "mmt_dropout_mask": (C.c_int, [fptr, C.c_long, C.c_float, fptr, C.c_uint32, C.c_void_p]),
+    "mmt_rng_advance": (C.c_int, [fptr, C.c_void_p]),
+    "mmt_dropout_apply": (C.c_int, [fptr, fptr, C.c_float, fptr, C.c_long, C.c_void_p]),
     "mmt_attention_fwd": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "mmt_attention_bwd": (C.c_int, [C.POINTER(AttnArgs), fptr, C.c_long, C.c_long, fptr, C.c_long, C.c_long, fptr, fptr,
                                     C.c_long, C.c_long, C.c_void_p]),

@@ -39,8 +39,17 @@ def _rows(t, name):
     return t.stride(0)
 
 
+def _keep(t, name, shape):
+    """A dropout keep mask: uint8 view of ``shape`` with unit column stride -> row stride in bytes."""
+    _dev(t, name, torch.uint8)
+    if tuple(t.shape) != tuple(shape) or (t.shape[-1] > 1 and t.stride(-1) != 1):
+        raise MmtError(f"{name}: expected a uint8 view of shape {tuple(shape)} with unit column stride, got "
+                       f"{tuple(t.shape)} {t.stride()}")
+    return t.stride(0)
+
+
 def _gemm_args(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1,
-               part_stride=0, asum=None):
+               part_stride=0, asum=None, drop=None, drop_after_add=False, mask_scale=0.0, ln_drop=None):
     _dev(A, "A"), _dev(B, "B")
     M, K = A.shape
     K2, N = B.shape
@@ -76,8 +85,24 @@ def _gemm_args(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumula
             raise MmtError("gemm: ln_bwd rstd (M) / weight (K) must be contiguous vectors")
         g.ln_xhat, g.ln_rstd, g.ln_g, g.ln_dx, g.ld_ln = xhat.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), \
             dx.data_ptr(), _rows(xhat, "xhat")
+    if mask_scale:
+        g.mask_scale = float(mask_scale)
+    if drop is not None:            # (keep bytes (M,N), scale)
+        keep, scale = drop
+        g.drop, g.ld_drop, g.drop_scale = keep.data_ptr(), _keep(keep, "drop", (M, N)), float(scale)
+        g.drop_after_add = int(bool(drop_after_add))
+    if ln_drop is not None:         # (keep bytes (M,K), scale, masked copy (M,K) laid out like dx)
+        if ln_bwd is None:
+            raise MmtError("gemm: ln_drop goes with ln_bwd")
+        keep, scale, dxm = ln_drop
+        _dev(dxm, "dxm")
+        if tuple(dxm.shape) != (M, K) or _rows(dxm, "dxm") != g.ld_ln:
+            raise MmtError("gemm: ln_drop's masked copy must be laid out like dx")
+        g.ln_drop, g.ld_ln_drop, g.ln_dxm, g.ln_drop_scale = keep.data_ptr(), _keep(keep, "ln_drop", (M, K)), dxm.data_ptr(), \
+            float(scale)
     if splitk > 1 or asum is not None:
-        if bias is not None or addend is not None or mask is not None or relu or accumulate or ln_bwd is not None:
+        if bias is not None or addend is not None or mask is not None or relu or accumulate or ln_bwd is not None \
+                or drop is not None:
             raise MmtError("gemm: splitk / asum cannot be combined with an epilogue")
         g.splitk, g.part_stride = int(splitk), int(part_stride)
         if asum is not None:
@@ -89,14 +114,18 @@ def _gemm_args(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumula
 
 
 def gemm(A, B, Cm, bias=None, addend=None, mask=None, relu=False, accumulate=False, ln_bwd=None, splitk=1,
-         part_stride=0, asum=None):
+         part_stride=0, asum=None, drop=None, drop_after_add=False, mask_scale=0.0, ln_drop=None):
     """Cm (+)= epi(A' @ B): A (M,K) and B (K,N) are arbitrary-stride views, Cm (M,N) has unit column stride.
     epi(v) = v + bias[n] + addend[m,n] -> relu -> zero where mask[m,n] <= 0.
     ``ln_bwd=(xhat, rstd, g, dx)``: A is the gradient at a LayerNorm output and A' = its LayerNorm backward (the
     input gradient, also stored to ``dx``), fused into the operand load; without it A' = A.
     ``splitk`` > 1 (weight gradients): slice z of the K range writes its partial to ``Cm`` + z*``part_stride`` floats
-    (same for ``asum``), the caller sums the slices; ``asum`` (M) receives the row sums of A (the bias gradient)."""
-    g = _gemm_args(A, B, Cm, bias, addend, mask, relu, accumulate, ln_bwd, splitk, part_stride, asum)
+    (same for ``asum``), the caller sums the slices; ``asum`` (M) receives the row sums of A (the bias gradient).
+    ``drop=(keep, scale)`` (training-mode dropout, keep = uint8 (M,N)): epi(v) = keep*scale*[relu](v + bias) + addend, or
+    keep*scale*(v + bias + addend) with ``drop_after_add``.  ``mask_scale``: outputs passing ``mask`` are multiplied by it.
+    ``ln_drop=(keep, scale, dxm)`` with ``ln_bwd``: the multiplied operand is keep*scale*A', also stored to ``dxm``."""
+    g = _gemm_args(A, B, Cm, bias, addend, mask, relu, accumulate, ln_bwd, splitk, part_stride, asum, drop, drop_after_add,
+                   mask_scale, ln_drop)
     lib = _lib.load()
     _lib.check(lib.mmt_gemm(C.byref(g), _stream()), "mmt_gemm")
 
@@ -107,11 +136,12 @@ def gemm_attention_bwd_ok(A, nhead, Lk, dh):
     return M <= 256 and K % 16 == 0 and K <= 256 and dh == 32 and 1 <= Lk <= 16
 
 
-def gemm_attention_bwd(A, B, q, k, v, probs, dq, dk, dv, nhead, scale, ln_bwd=None, probs_strides=None):
+def gemm_attention_bwd(A, B, q, k, v, probs, dq, dk, dv, nhead, scale, ln_bwd=None, probs_strides=None, ln_drop=None,
+                       pdrop=None):
     """d_o = A' @ B (A' as in ``gemm``, no epilogue) is consumed in place by ``attention_bwd`` with one query per batch
     element: dq (=), dk (+=), dv (+=); d_o itself is not stored."""
-    g = _gemm_args(A, B, None, ln_bwd=ln_bwd)
-    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale, probs_strides=probs_strides)
+    g = _gemm_args(A, B, None, ln_bwd=ln_bwd, ln_drop=ln_drop)
+    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale, probs_strides=probs_strides, pdrop=pdrop)
     Bn, Lq, d = q.shape
     Lk = k.shape[1]
     if Lq != 1 or g.M != Bn or g.N != d:
@@ -210,8 +240,9 @@ def layernorm_fwd(x, res, g, b, y, xhat, rstd, relu=False):
                                      _p(xhat), _p(rstd), _stream()), "mmt_layernorm_fwd")
 
 
-def layernorm_bwd(dy, xhat, rstd, g, dx, y_relu=None, dy_masked=None, accumulate=False):
-    """dx (+)= LayerNorm backward of dy (zeroed where y_relu <= 0); the masked dy goes to dy_masked."""
+def layernorm_bwd(dy, xhat, rstd, g, dx, y_relu=None, dy_masked=None, accumulate=False, drop=None):
+    """dx (+)= LayerNorm backward of dy (zeroed where y_relu <= 0); the masked dy goes to dy_masked.
+    ``drop=(keep, scale, dxm)``: dxm = keep*scale*dx (the gradient entering a dropped sub-layer output)."""
     M, N = dy.shape
     for t, n in ((dy, "dy"), (xhat, "xhat"), (dx, "dx")):
         _contig2(t, n, (M, N))
@@ -220,9 +251,15 @@ def layernorm_bwd(dy, xhat, rstd, g, dx, y_relu=None, dy_masked=None, accumulate
         _contig2(y_relu, "y_relu", (M, N))
     if dy_masked is not None:
         _contig2(dy_masked, "dy_masked", (M, N))
+    keep, kscale, dxm = (None, 0.0, None) if drop is None else drop
+    if drop is not None:
+        _contig2(dxm, "dxm", (M, N))
+        if _keep(keep, "drop", (M, N)) != N:
+            raise MmtError("layernorm_bwd: the keep mask must be contiguous")
     lib = _lib.load()
     _lib.check(lib.mmt_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(_dev(g, "g")), _p(y_relu), M, N, _p(dx),
-                                     int(bool(accumulate)), _p(dy_masked), _stream()), "mmt_layernorm_bwd")
+                                     int(bool(accumulate)), _p(dy_masked), _p(keep), float(kscale), _p(dxm), _stream()),
+               "mmt_layernorm_bwd")
 
 
 def _bld(t, name, B, L, d):
@@ -233,7 +270,7 @@ def _bld(t, name, B, L, d):
     return t.stride(0), t.stride(1)
 
 
-def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None, probs_strides=None):
+def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None, probs_strides=None, pdrop=None):
     B, Lq, d = q.shape
     Lk = k.shape[1]
     a = _lib.AttnArgs()
@@ -254,6 +291,12 @@ def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None,
         if not probs.is_contiguous() or probs.numel() < (B * nhead - 1) * a.p_hs + (Lq - 1) * a.p_rs + Lk:
             raise MmtError("probs: the strided stash is smaller than the rows addressed")
     a.probs = probs.data_ptr()
+    if pdrop is not None:       # (keep bytes laid out and offset exactly like ``probs``, scale)
+        keep, pscale = pdrop
+        _dev(keep, "pdrop", torch.uint8)
+        if not keep.is_contiguous() or keep.numel() != probs.numel():
+            raise MmtError("pdrop: the keep mask must be contiguous and as large as the probs stash it shadows")
+        a.pdrop, a.pdrop_scale = keep.data_ptr(), float(pscale)
     if pad is not None:
         _dev(pad, "pad", torch.uint8)
         if tuple(pad.shape) != (B, Lk) or not pad.is_contiguous():
@@ -266,19 +309,20 @@ def _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=None,
     return a
 
 
-def attention_fwd(q, k, v, o, probs, nhead, scale, pad=None, causal=False, causal_offset=0):
+def attention_fwd(q, k, v, o, probs, nhead, scale, pad=None, causal=False, causal_offset=0, probs_strides=None, pdrop=None):
     """o = softmax(scale * q k^T + masks) v per head; q,o (B,Lq,d) and k,v (B,Lk,d) strided views; the
-    probabilities (B,H,Lq,Lk) are stashed (zero at masked keys)."""
-    a = _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=o)
+    probabilities (B,H,Lq,Lk) are stashed (zero at masked keys).  ``pdrop=(keep, scale)``: dropout on the probabilities
+    (o uses keep*scale*softmax, the stash keeps the softmax)."""
+    a = _attn_args(q, k, v, probs, pad, nhead, causal, causal_offset, scale, o=o, probs_strides=probs_strides, pdrop=pdrop)
     lib = _lib.load()
     _lib.check(lib.mmt_attention_fwd(C.byref(a), _stream()), "mmt_attention_fwd")
 
 
-def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale, probs_strides=None):
+def attention_bwd(q, k, v, probs, d_o, dq, dk, dv, nhead, scale, probs_strides=None, pdrop=None):
     """dq (=), dk (+=), dv (+=) from d_o and the stashed probabilities; dk and dv must share strides.
     ``probs_strides`` = (stride between (b,h) slabs, stride between query rows) when ``probs`` starts inside a
     larger (B,H,Lq',Lk') stash."""
-    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale, probs_strides=probs_strides)
+    a = _attn_args(q, k, v, probs, None, nhead, False, 0, scale, probs_strides=probs_strides, pdrop=pdrop)
     B, Lq, d = q.shape
     Lk = k.shape[1]
     do_bs, do_rs = _bld(d_o, "d_o", B, Lq, d)
@@ -310,6 +354,32 @@ def history_prepare(x_st, x0, pad):
         raise MmtError("pad: expected a contiguous (B,T) uint8 tensor")
     lib = _lib.load()
     _lib.check(lib.mmt_history_prepare(_p(x_st), B * T, n, _p(x0), _p(pad), _stream()), "mmt_history_prepare")
+
+
+def dropout_mask(keep, p, rng_state, stream_id):
+    """keep (uint8, contiguous, a multiple of 4 elements) <- Bernoulli(1-p) bytes from Philox4x32-10 keyed by the device
+    words ``rng_state`` = int64 [seed, step] and ``stream_id``."""
+    _dev(keep, "keep", torch.uint8), _dev(rng_state, "rng_state", torch.int64)
+    if not keep.is_contiguous() or keep.numel() % 4 or rng_state.numel() != 2:
+        raise MmtError("dropout_mask: keep must be contiguous with a multiple of 4 elements, rng_state two int64 words")
+    lib = _lib.load()
+    _lib.check(lib.mmt_dropout_mask(_p(keep), keep.numel(), float(p), _p(rng_state), int(stream_id), _stream()), "mmt_dropout_mask")
+
+
+def rng_advance(rng_state):
+    _dev(rng_state, "rng_state", torch.int64)
+    lib = _lib.load()
+    _lib.check(lib.mmt_rng_advance(_p(rng_state), _stream()), "mmt_rng_advance")
+
+
+def dropout_apply(x, keep, scale, y):
+    """y = keep ? x*scale : 0 for contiguous tensors of one shape (y may be x)."""
+    _contig2(x, "x"), _contig2(y, "y", x.shape)
+    _dev(keep, "keep", torch.uint8)
+    if not keep.is_contiguous() or keep.numel() != x.numel():
+        raise MmtError("dropout_apply: the keep mask must be contiguous and as large as x")
+    lib = _lib.load()
+    _lib.check(lib.mmt_dropout_apply(_p(x), _p(keep), float(scale), _p(y), x.numel(), _stream()), "mmt_dropout_apply")
 
 
 def adamw_table(entries, device):

@@ -35,6 +35,31 @@ namespace {
 // SPLIT (weight gradients, both operands row-major in the reduction dimension): blockIdx.z owns a 64-aligned slice of the
 // K range and writes its partial to C + z*part_stride; the workgroups of the first column block also reduce the row sums
 // of their A tile (asum: the bias gradient) from the registers the tile passes through anyway.
+// epilogue of every GEMM kernel below; v = the accumulated product of output (m, n)
+__device__ __forceinline__ float gemm_epi(const mmt_gemm_args &g, float v, int m, int n) {
+  if (g.bias) v += g.bias[n];
+  if (g.drop) {
+    const float keep = g.drop[(size_t)m * g.ld_drop + n] ? g.drop_scale : 0.f;
+    if (g.drop_after_add) {
+      if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+      v *= keep;
+    } else {
+      if (g.relu) v = fmaxf(v, 0.f);
+      v *= keep;
+      if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+    }
+  } else {
+    if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
+    if (g.relu) v = fmaxf(v, 0.f);
+  }
+  if (g.mask) {
+    if (!(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+    else if (g.mask_scale != 0.f) v *= g.mask_scale;
+  }
+  return v;
+}
+__device__ __forceinline__ float keep_of(uint32_t bytes, int e, float scale) { return ((bytes >> (8 * e)) & 0xffu) ? scale : 0.f; }
+
 template <int BT, bool AK, bool BK, bool SPLIT = false>
 __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
   constexpr int KC = 64, LDK = KC + 4, LDR = BT + 4;
@@ -137,15 +162,11 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
     for (int j = 0; j < WT; ++j) {
       const int n = n0 + wn + 16 * j + (lane & 15);
       if (n >= g.N) continue;
-      const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
         if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
-        if (g.relu) v = fmaxf(v, 0.f);
-        if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+        const float v = gemm_epi(g, acc[i][j][r], m, n);
         float *cp = g.C + (size_t)m * g.ldc + n;
         *cp = g.accumulate ? (*cp + v) : v;
       }
@@ -246,7 +267,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
   }
   // attention operands of (agent m0 + tid/16, head blockIdx.x), lane l16 = tid % 16
   const int ab = m0 + (tid >> 4), l16 = tid & 15;
-  float kr[ATT ? 16 : 1][2], dkr[ATT ? 16 : 1][2], dvr[ATT ? 16 : 1][2], qd[2] = {0.f, 0.f}, pk = 0.f;
+  float kr[ATT ? 16 : 1][2], dkr[ATT ? 16 : 1][2], dvr[ATT ? 16 : 1][2], qd[2] = {0.f, 0.f}, pk = 0.f, pkeep = 1.f;
   f32x4 vrow[ATT ? 8 : 1];
   int Lk = 0;
   if constexpr (ATT) {
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     for (int c = 0; c < 8; ++c) vrow[c] = bl4(rv, l16 < Lk ? (vb + (unsigned)(l16 * (int)a.v_rs + 4 * c)) * 4u : OOB);
     ld_dpl<2>(qd, mk_rsrc(a.q), Lk > 0 ? (unsigned)(ab * (int)a.q_bs + h * 32 + l16 * 2) * 4u : OOB);
     pk = bl1(mk_rsrc(a.probs), l16 < Lk ? (unsigned)((ab * a.H + h) * (int)a.p_hs + l16) * 4u : OOB);
+    if (a.pdrop) pkeep = (l16 < Lk && a.pdrop[(size_t)(ab * a.H + h) * a.p_hs + l16]) ? a.pdrop_scale : 0.f;
   }
   if constexpr (LN) {
     const float rstd = mok ? g.ln_rstd[m] : 0.f;
@@ -296,6 +318,13 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       const int c = 4 * i + w;
       if (blockIdx.x == 0 && g.ln_dx && c < nch && mok)
         *reinterpret_cast<f32x4 *>(g.ln_dx + (size_t)m * g.ld_ln + 16 * c + 4 * kq) = a[i];
+      if (g.ln_drop) {     // the sub-layer's output was dropped before the residual add: its gradient is keep * A'
+        const uint32_t kb = (c < nch && mok) ? *reinterpret_cast<const uint32_t *>(g.ln_drop + (size_t)m * g.ld_ln_drop + 16 * c + 4 * kq) : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[i][e] *= keep_of(kb, e, g.ln_drop_scale);
+        if (blockIdx.x == 0 && g.ln_dxm && c < nch && mok)
+          *reinterpret_cast<f32x4 *>(g.ln_dxm + (size_t)m * g.ld_ln + 16 * c + 4 * kq) = a[i];
+      }
     }
   }
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -331,14 +360,15 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       dp = fmaf(grow[4 * c + 2], vrow[c][2], dp);
       dp = fmaf(grow[4 * c + 3], vrow[c][3], dp);
     }
-    const float dP = pk > 0.f ? dp : 0.f;
+    const float dP = pk > 0.f ? dp * pkeep : 0.f;     // (pkeep = 1 without dropout on the probabilities)
     const float dot = row16_sum(pk * dP);
     const float ds = pk * (dP - dot) * a.scale;
     const float gd[2] = {grow[l16 * 2], grow[l16 * 2 + 1]};
     float dqa[2] = {0.f, 0.f};
+    const float pkd = pk * pkeep;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {          // masked / absent keys carry p = ds = 0: exact no-ops
-      const float pj = __shfl(pk, j, 16), dsj = __shfl(ds, j, 16);
+      const float pj = __shfl(pkd, j, 16), dsj = __shfl(ds, j, 16);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         dqa[e] = fmaf(dsj, kr[j][e], dqa[e]);
@@ -370,11 +400,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     const int mm = m0 + row, n = n0 + 16 * t + col;
     if (mm >= g.M || n >= g.N) continue;
     const int ix = row * 17 + col;
-    float v = ((red[0][t][ix] + red[1][t][ix]) + red[2][t][ix]) + red[3][t][ix];
-    if (g.bias) v += g.bias[n];
-    if (g.addend) v += g.addend[(size_t)mm * g.ld_add + n];
-    if (g.relu) v = fmaxf(v, 0.f);
-    if (g.mask && !(g.mask[(size_t)mm * g.ld_mask + n] > 0.f)) v = 0.f;
+    const float v = gemm_epi(g, ((red[0][t][ix] + red[1][t][ix]) + red[2][t][ix]) + red[3][t][ix], mm, n);
     float *cp = g.C + (size_t)mm * g.ldc + n;
     *cp = g.accumulate ? (*cp + v) : v;
   }
@@ -401,11 +427,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_thin_kernel(mmt_gemm_args g) {
   for (int k = lane; k < g.K; k += 64) s = fmaf(A[(size_t)k * g.sak], B[(size_t)k * g.sbk], s);
   s = wave64_sum(s);
   if (lane == 0) {
-    float v = s;
-    if (g.bias) v += g.bias[n];
-    if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
-    if (g.relu) v = fmaxf(v, 0.f);
-    if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+    const float v = gemm_epi(g, s, m, n);
     float *cp = g.C + (size_t)m * g.ldc + n;
     *cp = g.accumulate ? (*cp + v) : v;
   }
@@ -477,15 +499,11 @@ __global__ __launch_bounds__(256) void mmt_gemm_kernel(mmt_gemm_args g) {
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn + 16 * j + (lane & 15);
       if (n >= g.N) continue;
-      const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
         if (m >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.addend) v += g.addend[(size_t)m * g.ld_add + n];
-        if (g.relu) v = fmaxf(v, 0.f);
-        if (g.mask && !(g.mask[(size_t)m * g.ld_mask + n] > 0.f)) v = 0.f;
+        const float v = gemm_epi(g, acc[i][j][r], m, n);
         float *c = g.C + (size_t)m * g.ldc + n;
         *c = g.accumulate ? (*c + v) : v;
       }
@@ -599,7 +617,8 @@ __global__ __launch_bounds__(256) void mmt_ln_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ rstd, const float *__restrict__ g,
                                                          const float *__restrict__ y_relu, int M, int N,
                                                          float *__restrict__ dx, int accumulate,
-                                                         float *__restrict__ dy_masked) {
+                                                         float *__restrict__ dy_masked, const uint8_t *__restrict__ drop,
+                                                         float drop_scale, float *__restrict__ dxm) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const size_t o = (size_t)row * N;
@@ -623,6 +642,7 @@ __global__ __launch_bounds__(256) void mmt_ln_bwd_kernel(const float *__restrict
     if (!dy_masked && y_relu && !(y_relu[o + c] > 0.f)) d = 0.f;
     const float v = rs * (d * g[c] - m1 - xhat[o + c] * m2);
     dx[o + c] = accumulate ? dx[o + c] + v : v;
+    if (drop) dxm[o + c] = drop[o + c] ? v * drop_scale : 0.f;
   }
 }
 
@@ -676,6 +696,11 @@ __global__ __launch_bounds__(256) void mmt_attn_fwd_kernel(mmt_attn_args a) {
     float *P = a.probs + (size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs;
     if (l16 < a.Lk) P[l16] = p0;
     if (l16 + 16 < a.Lk) P[l16 + 16] = p1;
+    if (a.pdrop) {       // the stash keeps the softmax; the output uses keep * softmax
+      const uint8_t *D = a.pdrop + (size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs;
+      p0 *= (l16 < a.Lk && D[l16]) ? a.pdrop_scale : 0.f;
+      p1 *= (l16 + 16 < a.Lk && D[l16 + 16]) ? a.pdrop_scale : 0.f;
+    }
   }
   float o[DPL];
 #pragma unroll
@@ -724,11 +749,14 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
     f32x4 gv[NQ];
 #pragma unroll
     for (int c = 0; c < NQ; ++c) gv[c] = *reinterpret_cast<const f32x4 *>(g + 4 * c);
-    float p[2] = {0.f, 0.f}, dP[2] = {0.f, 0.f};
+    const uint8_t *D = a.pdrop ? a.pdrop + (size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs : nullptr;
+    float p[2] = {0.f, 0.f}, dP[2] = {0.f, 0.f}, pd[2] = {0.f, 0.f};
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const int j = l16 + 16 * hf;
       if (j < Lk) p[hf] = P[j];
+      const float keep = (D && j < Lk) ? (D[j] ? a.pdrop_scale : 0.f) : 1.f;
+      pd[hf] = p[hf] * keep;
       if (p[hf] > 0.f) {
         const float *vj = V + (size_t)j * a.v_rs;
         float t = 0.f;
@@ -740,7 +768,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
           t = fmaf(gv[c][2], vv[2], t);
           t = fmaf(gv[c][3], vv[3], t);
         }
-        dP[hf] = t;
+        dP[hf] = t * keep;
       }
     }
     const float dot = row16_sum(fmaf(p[0], dP[0], p[1] * dP[1]));
@@ -754,6 +782,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
     }
     for (int j = 0; j < 32; ++j) {
       const float pj = __shfl(j < 16 ? p[0] : p[1], j & 15, 16), dsj = __shfl(j < 16 ? ds0 : ds1, j & 15, 16);
+      const float pdj = __shfl(j < 16 ? pd[0] : pd[1], j & 15, 16);
       if (j < Lk && pj > 0.f) {
         const float *kj = K + (size_t)j * a.k_rs + l16 * DPL;
         float *dkj = dK + (size_t)j * dk_rs, *dvj = dV + (size_t)j * dk_rs;
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd_kernel(mmt_attn_args a, cons
         for (int e = 0; e < DPL; ++e) {
           dqa[e] = fmaf(dsj, kj[e], dqa[e]);
           dkj[e] = fmaf(dsj, qd[e], dkj[e]);
-          dvj[e] = fmaf(pj, gd[e], dvj[e]);
+          dvj[e] = fmaf(pdj, gd[e], dvj[e]);
         }
       }
     }
@@ -809,6 +838,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, co
     const float *q = a.q + (size_t)b * a.q_bs + (size_t)i * a.q_rs + h * DH;
     const float *g = dO + (size_t)b * do_bs + (size_t)i * do_rs + h * DH;
     const float p = l16 < Lk ? P[l16] : 0.f;
+    const float keep = (a.pdrop && l16 < Lk) ? (a.pdrop[(size_t)(b * a.H + h) * a.p_hs + (size_t)i * a.p_rs + l16] ? a.pdrop_scale : 0.f) : 1.f;
     float t = 0.f;
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
@@ -818,9 +848,10 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, co
       t = fmaf(gv[2], vrow[c][2], t);
       t = fmaf(gv[3], vrow[c][3], t);
     }
-    const float dP = p > 0.f ? t : 0.f;
+    const float dP = p > 0.f ? t * keep : 0.f;
     const float dot = row16_sum(p * dP);
     const float ds = p * (dP - dot) * a.scale;
+    const float pdrop = p * keep;
     float qd[DPL], gd[DPL], dqa[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) {
@@ -830,7 +861,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, co
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {       // masked / absent keys carry p = ds = 0: the updates are exact no-ops
-      const float pj = __shfl(p, j, 16), dsj = __shfl(ds, j, 16);
+      const float pj = __shfl(pdrop, j, 16), dsj = __shfl(ds, j, 16);
 #pragma unroll
       for (int e = 0; e < DPL; ++e) {
         dqa[e] = fmaf(dsj, kr[j][e], dqa[e]);
@@ -1062,6 +1093,39 @@ __global__ void mmt_copy3_kernel(const float *__restrict__ src, long sbs, long s
   }
 }
 
+// ------------------------------------------------------------------------------------------ dropout masks
+// Philox4x32-10 (Salmon et al., SC'11): counter (element index / 4, mask stream, step), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0, c[1] = lo1, c[2] = n2, c[3] = lo0;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(256) void mmt_dropout_mask_kernel(uint32_t *__restrict__ keep4, long n4, uint32_t threshold,
+                                                               const uint64_t *__restrict__ rng, uint32_t stream_id) {
+  const uint64_t seed = rng[0], step = rng[1];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32) ^ (stream_id << 8), (uint32_t)step, (uint32_t)(step >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t out = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out |= (c[e] >= threshold ? 1u : 0u) << (8 * e);
+    keep4[i] = out;
+  }
+}
+__global__ void mmt_rng_advance_kernel(uint64_t *rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
+}
+__global__ __launch_bounds__(256) void mmt_dropout_apply_kernel(const float *__restrict__ x, const uint8_t *__restrict__ keep, float scale,
+                                                                float *__restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = keep[i] ? x[i] * scale : 0.f;
+}
+
 __global__ void mmt_lr_step_kernel(float *state, float gamma) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     state[0] += 1.0f;
@@ -1087,9 +1151,13 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   const double amax = (double)g->M * (double)(ak ? g->sam : 1) + (double)g->K * (double)(ak ? 1 : g->sak);
   const double bmax = (double)g->N * (double)(bk ? g->sbn : 1) + (double)g->K * (double)(bk ? 1 : g->sbk);
   hipStream_t st = (hipStream_t)stream;
+  if (g->drop && (g->ld_drop < g->N || g->accumulate || (g->drop_after_add && g->relu)))
+    return mmt_set_error(MMT_EINVAL, "mmt_gemm: dropout needs ld_drop >= N, no accumulate, and relu only before the addend");
+  if (g->ln_drop && (!g->ln_xhat || ((uintptr_t)g->ln_drop & 3) || (g->ld_ln_drop & 3) || ((uintptr_t)g->ln_dxm & 15)))
+    return mmt_set_error(MMT_EINVAL, "mmt_gemm: ln_drop goes with the fused LayerNorm backward, 4-byte aligned keep rows");
   if (g->splitk > 1 || g->asum) {
     if (!(aligned && ar && br && amax < 5e8 && bmax < 5e8) || g->bias || g->addend || g->mask || g->relu || g->accumulate ||
-        g->ln_xhat || g->splitk > 16 || (g->splitk > 1 && g->part_stride <= 0))
+        g->ln_xhat || g->drop || g->splitk > 16 || (g->splitk > 1 && g->part_stride <= 0))
       return mmt_set_error(MMT_EINVAL, "mmt_gemm: splitk / asum need A and B with unit stride along their rows (M, N "
                                        "multiples of 4, 16-byte aligned), no epilogue, splitk <= 16");
     launch_split(*g, st);
@@ -1135,7 +1203,8 @@ extern "C" int mmt_gemm_attention_bwd(const mmt_gemm_args *g, const mmt_attn_arg
   const bool aligned = (((uintptr_t)g->A | (uintptr_t)g->B) & 15) == 0;
   const bool shape = ak && g->sbn == 1 && g->K % 16 == 0 && g->K <= 256 && g->M <= 256 && g->M == a->B && a->Lq == 1 && a->dh == 32 &&
                      g->N == a->H * 32 && a->Lk >= 1 && a->Lk <= 16;
-  const bool plain = !g->bias && !g->addend && !g->mask && !g->relu && !g->accumulate && g->splitk <= 1 && !g->asum;
+  const bool plain = !g->bias && !g->addend && !g->mask && !g->relu && !g->accumulate && g->splitk <= 1 && !g->asum && !g->drop &&
+                     (!g->ln_drop || (g->ln_xhat && !((uintptr_t)g->ln_drop & 3) && !(g->ld_ln_drop & 3) && !((uintptr_t)g->ln_dxm & 15)));
   const bool attn_ok = a->q && a->k && a->v && a->probs && (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)dk |
                                                              (uintptr_t)dv | (uintptr_t)dq) & 15) == 0 &&
                        ((a->q_bs | a->k_bs | a->k_rs | a->v_bs | a->v_rs | dk_bs | dk_rs | dq_bs) & 3) == 0 && a->p_hs >= a->Lk &&
@@ -1213,10 +1282,13 @@ extern "C" int mmt_layernorm_fwd(const float *x, const float *res, int M, int N,
 }
 
 extern "C" int mmt_layernorm_bwd(const float *dy, const float *xhat, const float *rstd, const float *g, const float *y_relu,
-                                 int M, int N, float *dx, int accumulate, float *dy_masked, void *stream) {
+                                 int M, int N, float *dx, int accumulate, float *dy_masked, const uint8_t *drop, float drop_scale,
+                                 float *dx_dropped, void *stream) {
   if (!dy || !xhat || !rstd || !g || !dx || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_layernorm_bwd: bad arguments");
+  if ((drop != nullptr) != (dx_dropped != nullptr) || (drop && accumulate))
+    return mmt_set_error(MMT_EINVAL, "mmt_layernorm_bwd: drop and dx_dropped go together, and not with accumulate");
   hipLaunchKernelGGL(mmt_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, g, y_relu, M, N,
-                     dx, accumulate, dy_masked);
+                     dx, accumulate, dy_masked, drop, drop_scale, dx_dropped);
   return launch_ok("mmt_layernorm_bwd");
 }
 
@@ -1287,6 +1359,27 @@ extern "C" int mmt_history_prepare(const float *x_st, int rows, int n_in, float 
   hipLaunchKernelGGL(mmt_history_prepare_kernel, dim3((rows * n_in + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_st, rows,
                      n_in, x0, pad);
   return launch_ok("mmt_history_prepare");
+}
+
+extern "C" int mmt_dropout_mask(uint8_t *keep, long n, float p, const uint64_t *rng_state, uint32_t stream_id, void *stream) {
+  if (!keep || !rng_state || n <= 0 || (n & 3) || ((uintptr_t)keep & 3) || !(p >= 0.f && p < 1.f) || stream_id >= (1u << 24))
+    return mmt_set_error(MMT_EINVAL, "mmt_dropout_mask: need n > 0 a multiple of 4, a 4-byte aligned buffer, 0 <= p < 1");
+  const uint32_t threshold = (uint32_t)std::min(4294967295.0, (double)p * 4294967296.0);
+  const long n4 = n >> 2;
+  hipLaunchKernelGGL(mmt_dropout_mask_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<uint32_t *>(keep), n4, threshold, rng_state, stream_id);
+  return launch_ok("mmt_dropout_mask");
+}
+extern "C" int mmt_rng_advance(uint64_t *rng_state, void *stream) {
+  if (!rng_state) return mmt_set_error(MMT_EINVAL, "mmt_rng_advance: null state");
+  hipLaunchKernelGGL(mmt_rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng_state);
+  return launch_ok("mmt_rng_advance");
+}
+extern "C" int mmt_dropout_apply(const float *x, const uint8_t *keep, float scale, float *y, long n, void *stream) {
+  if (!x || !keep || !y || n <= 0) return mmt_set_error(MMT_EINVAL, "mmt_dropout_apply: bad arguments");
+  hipLaunchKernelGGL(mmt_dropout_apply_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, x,
+                     keep, scale, y, n);
+  return launch_ok("mmt_dropout_apply");
 }
 
 extern "C" int mmt_lr_step(float *state_dev, float gamma, void *stream) {

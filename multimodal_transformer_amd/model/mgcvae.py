@@ -114,8 +114,6 @@ class MultimodalGenerativeCVAE(object):
         encoded_map = encoded_lane = None
         side = None
         if hp["map_cnn_encoding"] or hp["map_vit_encoding"]:
-            if mode == ModeKeys.TRAIN:
-                raise MmtError("training-mode dropout on the map feature is not implemented in the HIP path")
             # The map encoder does not depend on the history encoder, and each of them runs one workgroup per agent (tile): at the
             # benchmark batch (128 agents, 256 CUs) they fit on the chip side by side.  Fork to a second stream, join before the decode.
             if map.is_cuda:
@@ -138,7 +136,29 @@ class MultimodalGenerativeCVAE(object):
             emb = hp["lane_encoder"][self.node_type]["embedding_size"]
             flat = inputs_lane.contiguous().view(B * ln, emb, sn)     # raw reinterpretation (mgcvae.py:301-302)
             encoded_lane = self._m("lane_encoder")(flat).view(B, ln, -1)
+        if hp["map_cnn_encoding"] and mode == ModeKeys.TRAIN:
+            encoded_map = self._train_mode_map_dropout(encoded_map)
         return memory, None, pad, inputs_st[:, -1], inputs[:, -1, 0:2], encoded_lane, encoded_map
+
+    def _train_mode_map_dropout(self, encoded_map):
+        """``F.dropout(encoded_map, cnn_param.dropout, training=(mode == TRAIN))`` (mgcvae.py:291-293) with this package's
+        counter-based masks.  (The encoder / ViT dropouts of training mode live in the training step, training.py: this
+        function's kernels are the inference ones.)"""
+        from .. import _train_kernels as K
+        p = float(self.hyperparams["map_encoder"]["cnn_param"]["dropout"])
+        if p <= 0.0 or not self._m("map_encoder").training:
+            return encoded_map
+        dev = encoded_map.device
+        rng = self.__dict__.get("_map_rng")
+        if rng is None or rng.device != dev:
+            rng = self.__dict__["_map_rng"] = torch.tensor([int(self.__dict__.get("dropout_seed", 0)), 0], dtype=torch.int64).to(dev)
+        n = encoded_map.numel()
+        keep = torch.empty((n + 3) & ~3, dtype=torch.uint8, device=dev)
+        K.dropout_mask(keep, p, rng, 0xFFFF)
+        K.rng_advance(rng)
+        out = torch.empty_like(encoded_map, memory_format=torch.contiguous_format)
+        K.dropout_apply(encoded_map.contiguous(), keep[:n], 1.0 / (1.0 - p), out)
+        return out
 
     def at_dec(self, memory, memory_mask, memory_key_padding_mask, n_s_t0, lane_feature, map_feature,
                prediction_horizon):

@@ -385,6 +385,7 @@ class ViT(_PackedMixin, nn.Module):
         self.to_patch_embedding = nn.Sequential(nn.Identity(), nn.Linear(channels * patch_size ** 2, dim))
         self.pos_embedding = nn.Parameter(torch.randn(1, n_patches + 1, dim))
         self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)         # (training step only: training.py; the inference kernels are eval-mode)
         blocks = []
         for _ in range(depth):
             attn = nn.Module()

@@ -14,8 +14,16 @@ All buffers are allocated once per (B, T, ph); a whole step launches ~2000 small
 HIP graph.  Parameters are used in place (natural nn.Linear layout); gradients live in one flat buffer (the
 all-reduce bucket) whose slices are the per-parameter ``.grad`` views.
 
-Dropout: the HIP training step implements the dropout-free graph, the configuration training parity is defined
-on (the reference's dropout RNG stream is not a meaningful parity target).
+Dropout (Transformer_model.py:28-30,77-79,126-129; mgcvae.py:291-293; the ViT's 0.1 / 0.1): active when the modules are in
+training mode and their probabilities are > 0, exactly the state torch's own modules consult.  All keep masks of a step are
+drawn up front by one counter-based kernel per probability (Philox4x32-10 keyed by a device-resident {seed, step}: a replayed
+graph draws fresh masks) into a uint8 pool; the forward GEMM epilogues, the attention kernels and the backward read the same
+bytes.  One mask per stash position: the reference re-runs the whole decoder on the growing target with fresh masks for
+every pass (mgcvae.py:432-446); here position j of the KV-cached recurrence keeps its mask for the rest of the decode (the
+distribution of each activation is the same, the correlation between passes is not a parity target).
+With dropout the autoregressive tokens depend on the masks, so the decode runs step by step on the stash kernels instead of
+the inference decoder kernels.  With every probability 0 (or modules in eval mode) the dropout-free graph runs, bit for bit
+the one training parity is defined on.
 """
 from __future__ import annotations
 
@@ -67,14 +75,17 @@ class _MlpTape:
     def _f2(self, t):
         return t.view(self.R, t.shape[-1])
 
-    def forward_hidden(self, zin):
-        """zin (R, k_in) -> input of the output Linear (R, n); keeps what the backward reads."""
+    def forward_hidden(self, zin, rows=None):
+        """zin (R, k_in) -> input of the output Linear (R, n); keeps what the backward reads.  ``rows=(r0, r1)``: zin holds
+        rows r0..r1-1 only (one step of a step-by-step decode)."""
+        r0, r1 = rows if rows is not None else (0, self.R)
         z = zin
         for i, (lin, ln) in enumerate(self.hidden):
-            K.gemm(z, _t(lin.weight), self.tmp, bias=lin.bias)
-            K.layernorm_fwd(self.tmp, None, ln.weight, ln.bias, self._f2(self.hu[i]), self._f2(self.hxhat[i]),
-                            self.hrstd[i].view(self.R), relu=True)
-            z = self._f2(self.hu[i])
+            tmp = self.tmp[r0:r1]
+            K.gemm(z, _t(lin.weight), tmp, bias=lin.bias)
+            K.layernorm_fwd(tmp, None, ln.weight, ln.bias, self._f2(self.hu[i])[r0:r1], self._f2(self.hxhat[i])[r0:r1],
+                            self.hrstd[i].view(self.R)[r0:r1], relu=True)
+            z = self._f2(self.hu[i])[r0:r1]
         return z
 
     def forward_out(self, z, out, addend=None):
@@ -188,6 +199,7 @@ class _VitTape:
 
     def __init__(self, eng, vit, B, alpha=2.0, beta=-1.0):
         cfg = vit._cfg()
+        self.eng = eng
         self.vit, self.B, self.alpha, self.beta = vit, B, float(alpha), float(beta)
         self.S, self.P, self.C = cfg["image_size"], cfg["patch_size"], cfg["channels"]
         self.n = (self.S // self.P) ** 2
@@ -215,6 +227,10 @@ class _VitTape:
         self.xc, self.hc, self.xhatc, self.rstdc, self.out = b(B, d), b(B, d), b(B, d), b(B), b(B, self.n_out)
         self.gx, self.g_a, self.g_z, self.g_h, self.g_o = b(B, L, d), b(R, self.f), b(R, self.f), b(R, d), b(B, L, inner)
         self.g_hc, self.g_xc = b(B, d), b(B, d)
+        self.gxm = b(R, d)                                        # keep * gx where a sub-layer output was dropped
+
+    def _drop(self, name):
+        return self.eng.drop.view.get(name)
 
     def parameters(self):
         return self.vit.parameters()
@@ -234,17 +250,23 @@ class _VitTape:
         K.copy3(v.pos_embedding[:, :L].expand(B, L, d), x0)
         K.copy3(v.cls_token.expand(B, 1, d), x0[:, 0:1, :], accumulate=True)
         K.copy3(self.pe.view(B, n, d), x0[:, 1:, :], accumulate=True)
+        de = self._drop("vit.emb")
+        if de is not None:      # self.dropout(x) after the position embedding
+            K.dropout_apply(x0, de[0], de[1], x0)
         for i, T in enumerate(self.blocks):
             xin, xmid, xout = (self.x[2 * i + j].view(R, d) for j in range(3))
             K.layernorm_fwd(xin, None, T["ln1"].weight, T["ln1"].bias, T["h1"], T["xhat1"], T["rstd1"])
             K.gemm(T["h1"], _t(T["wqkv"]), T["qkv"].view(R, 3 * self.inner))
             q, k, vv = self._qkv(T["qkv"])
             K.attention_fwd(q, k, vv, T["o"], T["probs"], self.H, self.scale)
-            K.gemm(T["o"].view(R, self.inner), _t(T["wo"]), xmid, bias=T["bo"], addend=xin)
+            K.gemm(T["o"].view(R, self.inner), _t(T["wo"]), xmid, bias=T["bo"], addend=xin, drop=self._drop(f"vit{i}.out"))
             K.layernorm_fwd(xmid, None, T["ln2"].weight, T["ln2"].bias, T["h2"], T["xhat2"], T["rstd2"])
             K.gemm(T["h2"], _t(T["w1"]), T["z"], bias=T["b1"])
             K.gelu_fwd(T["z"], T["a"])
-            K.gemm(T["a"], _t(T["w2"]), xout, bias=T["b2"], addend=xmid)
+            d1 = self._drop(f"vit{i}.ff1")
+            if d1 is not None:
+                K.dropout_apply(T["a"], d1[0], d1[1], T["a"])
+            K.gemm(T["a"], _t(T["w2"]), xout, bias=T["b2"], addend=xmid, drop=self._drop(f"vit{i}.ff2"))
         K.copy3(self.x[-1][:, 0:1, :], self.xc.view(B, 1, d))                    # cls pooling
         ln, fc = v.mlp_head[0], v.mlp_head[1]
         K.layernorm_fwd(self.xc, None, ln.weight, ln.bias, self.hc, self.xhatc, self.rstdc)
@@ -264,18 +286,30 @@ class _VitTape:
         self.dqkv_all.zero_()
         K.copy3(self.g_xc.view(B, 1, d), self.gx[:, 0:1, :])
         gx = self.gx.view(R, d)
-        for T in reversed(self.blocks):
-            # x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
-            eng._wgrad_rows(gx, T["a"], eng.g(T["w2"]), eng.g(T["b2"]))
-            K.gemm(gx, T["w2"], self.g_a)
+        for i in range(len(self.blocks) - 1, -1, -1):
+            T = self.blocks[i]
+            # x_out = x_mid + drop(W2 drop(gelu(W1 LN2(x_mid) + b1)) + b2)
+            d2, d1, do = self._drop(f"vit{i}.ff2"), self._drop(f"vit{i}.ff1"), self._drop(f"vit{i}.out")
+            gy = gx
+            if d2 is not None:
+                K.dropout_apply(gx, d2[0], d2[1], self.gxm)
+                gy = self.gxm
+            eng._wgrad_rows(gy, T["a"], eng.g(T["w2"]), eng.g(T["b2"]))
+            K.gemm(gy, T["w2"], self.g_a)
+            if d1 is not None:
+                K.dropout_apply(self.g_a, d1[0], d1[1], self.g_a)
             K.gelu_bwd(T["z"], self.g_a, self.g_z)
             eng._wgrad_rows(self.g_z, T["h2"], eng.g(T["w1"]), eng.g(T["b1"]))
             K.gemm(self.g_z, T["w1"], self.g_h)
             eng._ln_grad(self.g_h, T["xhat2"], T["ln2"])
             K.layernorm_bwd(self.g_h, T["xhat2"], T["rstd2"], T["ln2"].weight, gx, accumulate=True)
-            # x_mid = x_in + Wo attention(LN1(x_in) Wqkv^T) + bo
-            eng._wgrad_rows(gx, T["o"].view(R, self.inner), eng.g(T["wo"]), eng.g(T["bo"]))
-            K.gemm(gx, T["wo"], self.g_o.view(R, self.inner))
+            # x_mid = x_in + drop(Wo attention(LN1(x_in) Wqkv^T) + bo)
+            gy = gx
+            if do is not None:
+                K.dropout_apply(gx, do[0], do[1], self.gxm)
+                gy = self.gxm
+            eng._wgrad_rows(gy, T["o"].view(R, self.inner), eng.g(T["wo"]), eng.g(T["bo"]))
+            K.gemm(gy, T["wo"], self.g_o.view(R, self.inner))
             q, k, vv = self._qkv(T["qkv"])
             dq, dk, dv = self._qkv(T["dqkv"])
             K.attention_bwd(q, k, vv, T["probs"], self.g_o, dq, dk, dv, self.H, self.scale)
@@ -284,7 +318,10 @@ class _VitTape:
             K.gemm(dqkv, T["wqkv"], self.g_h)
             eng._ln_grad(self.g_h, T["xhat1"], T["ln1"])
             K.layernorm_bwd(self.g_h, T["xhat1"], T["rstd1"], T["ln1"].weight, gx, accumulate=True)
-        # tokens = cat[cls, patches W^T + b] + pos
+        # tokens = drop(cat[cls, patches W^T + b] + pos)
+        de = self._drop("vit.emb")
+        if de is not None:
+            K.dropout_apply(self.gx, de[0], de[1], self.gx)
         gpos = eng.g(v.pos_embedding)
         K.colsum(self.gx.view(B, L * d), gpos.view(L * d))
         K.copy3(gpos.view(1, L, d)[:, 0:1, :], eng.g(v.cls_token).view(1, 1, d))
@@ -293,11 +330,76 @@ class _VitTape:
         eng._wgrad_rows(self.g_pe, self.patches, eng.g(lin.weight), eng.g(lin.bias))
 
 
+class _DropPlan:
+    """Keep masks of one training step: a site is (name, shape of the tensor it masks, probability).  Sites with p = 0 get no
+    mask (their kernels then run the dropout-free code path).  The pool is one uint8 buffer, sites of equal probability
+    contiguous, so that ``generate`` is one kernel launch per distinct probability."""
+
+    def __init__(self, device, seed=0):
+        self.device = device
+        self.want = []                 # (name, shape, p)
+        self.view = {}                 # name -> (uint8 view, 1/(1-p)) | None
+        self.regions = []              # (p, lo, hi) in pool bytes
+        self.pool = None
+        self.rng = torch.tensor([int(seed), 0], dtype=torch.int64).to(device)
+
+    def add(self, name, shape, p):
+        if name in self.view or any(n == name for n, _, _ in self.want):
+            raise MmtError(f"dropout site {name} registered twice")
+        if not (0.0 <= float(p) < 1.0):
+            raise MmtError(f"dropout probability {p} of {name} is outside [0, 1)")
+        if float(p) > 0.0:
+            self.want.append((name, tuple(int(v) for v in shape), float(p)))
+        else:
+            self.view[name] = None
+
+    def build(self):
+        total, by_p = 0, {}
+        for name, shape, p in self.want:
+            by_p.setdefault(p, []).append((name, shape))
+        layout = []
+        for p, sites in by_p.items():
+            lo = total
+            for name, shape in sites:
+                n = 1
+                for v in shape:
+                    n *= v
+                layout.append((name, shape, p, total, n))
+                total += (n + 15) & ~15
+            self.regions.append((p, lo, total))
+        self.pool = torch.zeros(max(total, 16), dtype=torch.uint8, device=self.device)
+        for name, shape, p, off, n in layout:
+            self.view[name] = (self.pool[off:off + n].view(shape), 1.0 / (1.0 - p))
+
+    @property
+    def active(self):
+        return bool(self.regions)
+
+    def get(self, name, index=None):
+        """(keep view, scale) of a site, optionally of one slice along its first axis; None when the site is not dropped."""
+        v = self.view[name]
+        if v is None or index is None:
+            return v
+        return v[0][index], v[1]
+
+    def seed(self, seed, step=0):
+        self.rng.copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
+
+    def generate(self):
+        for i, (p, lo, hi) in enumerate(self.regions):
+            K.dropout_mask(self.pool[lo:hi], p, self.rng, i)
+        K.rng_advance(self.rng)
+
+    def masks(self):
+        """{site: bool tensor} of the masks the last ``generate`` drew (tests inject them into the oracle)."""
+        return {n: (v[0] != 0) for n, v in self.view.items() if v is not None}
+
+
 class TrainEngine:
     """Forward-with-stash + backward for one (B, T, ph) shape of the Basic, Map_encoding_CNN, Map_encoding_ViT or
-    Lane_encoding_CNN configuration."""
+    Lane_encoding_CNN configuration.  ``dropout``: None = as the modules say (training mode and p > 0), False = never."""
 
-    def __init__(self, model, B, T, ph, device=None, teacher_forced=None):
+    def __init__(self, model, B, T, ph, device=None, teacher_forced=None, dropout=None, seed=0):
         hp = model.hyperparams
         # non_at_dec (mgcvae.py:310-373): tokens come from the labels, positions are the running sum of the head
         # outputs and are NOT fed back, so no gradient flows through the tokens
@@ -337,8 +439,53 @@ class TrainEngine:
         self.n_pos = self.dec.input_fc.weight.shape[1]
         self.n_out = self.dec.output_fc.weight.shape[0]
         self._pdec = None
+        self.hp = hp
+        self.use_dropout = bool(self.enc.training) if dropout is None else bool(dropout)
+        self.drop = _DropPlan(self.device, seed)
         self._collect_params(model)
+        self._plan_dropout()
         self._alloc()
+
+    # ------------------------------------------------------------------ dropout sites
+    def _plan_dropout(self):
+        """One site per nn.Dropout / F.dropout / attention-probability dropout the reference's modules apply in training mode,
+        shaped like the stash tensor it masks (decoder sites step-major, like the stash)."""
+        B, T, ph, d, H = self.B, self.T, self.ph, self.d, self.H
+        Re, on = B * T, self.use_dropout
+        P = lambda v: float(v) if on else 0.0
+        add = self.drop.add
+        add("enc.pe", (Re, d), P(self.enc.pos_encoder.dropout.p))
+        for l, lay in enumerate(self.enc.transformer_encoder.layers):
+            add(f"enc{l}.attn", (B * H * T * T,), P(lay.self_attn.dropout))
+            add(f"enc{l}.drop1", (Re, d), P(lay.dropout1.p))
+            add(f"enc{l}.ff", (Re, self.f_enc), P(lay.dropout.p))
+            add(f"enc{l}.drop2", (Re, d), P(lay.dropout2.p))
+        add("dec.pe", (ph, B, d), P(self.dec.pos_encoder.dropout.p))
+        for l, lay in enumerate(self.dec.transformer_decoder.layers):
+            add(f"dec{l}.attn1", (B * H * ph * ph,), P(lay.self_attn.dropout))
+            add(f"dec{l}.drop1", (ph, B, d), P(lay.dropout1.p))
+            add(f"dec{l}.attn2", (B * H * ph * T,), P(lay.multihead_attn.dropout))
+            add(f"dec{l}.drop2", (ph, B, d), P(lay.dropout2.p))
+            add(f"dec{l}.ff", (ph, B, self.f_dec), P(lay.dropout.p))
+            add(f"dec{l}.drop3", (ph, B, d), P(lay.dropout3.p))
+        if self.map_mode and not self.vit_mode:     # F.dropout(encoded_map, p, training=TRAIN), mgcvae.py:291-293
+            add("map.feature", (B, int(self.hp["map_encoder"]["cnn_param"]["output_size"])),
+                P(self.hp["map_encoder"]["cnn_param"]["dropout"]))
+        if self.vit_mode:
+            v = self.cnn
+            cfg = v._cfg()
+            Lv, dv = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1, cfg["dim"]
+            von = on and v.training
+            add("vit.emb", (B, Lv, dv), float(getattr(v, "dropout", torch.nn.Dropout(0.0)).p) if von else 0.0)
+            for i, (attn, ff) in enumerate(v.transformer.layers):
+                add(f"vit{i}.out", (B * Lv, dv), float(attn.fn.to_out[1].p) if von else 0.0)
+                add(f"vit{i}.ff1", (B * Lv, cfg["mlp_dim"]), float(ff.fn.net[2].p) if von else 0.0)
+                add(f"vit{i}.ff2", (B * Lv, dv), float(ff.fn.net[4].p) if von else 0.0)
+        self.drop.build()
+
+    def seed(self, seed, step=0):
+        """Seed of the dropout masks (the masks of step n are a function of (seed, n) only)."""
+        self.drop.seed(seed, step)
 
     # ------------------------------------------------------------------ parameters / gradients
     def _collect_params(self, model):
@@ -412,6 +559,10 @@ class TrainEngine:
         S.geh = [b(Re, d) for _ in range(self.Le + 1)]
         S.gef2, S.gef1 = [b(Re, d) for _ in range(self.Le)], [b(Re, fe) for _ in range(self.Le)]
         S.geh1, S.geo1 = [b(Re, d) for _ in range(self.Le)], [b(Re, d) for _ in range(self.Le)]
+        # gradient entering a sub-layer whose output was dropped before the residual add (= the plain one without dropout)
+        D = self.drop.get
+        S.gef2m = [b(Re, d) if D(f"enc{l}.drop2") else S.gef2[l] for l in range(self.Le)]
+        S.geo1m = [b(Re, d) if D(f"enc{l}.drop1") else S.geo1[l] for l in range(self.Le)]
         S.geatt = [b(Re, d) for _ in range(self.Le)]
         # the buffers that the attention backward kernels accumulate into (dK, dV += ...) share one pool: one fill per step
         L_ = self.Ld
@@ -453,6 +604,9 @@ class TrainEngine:
             S.ho = S.hcat[:, :, :no]                       # output_fc writes straight into its columns of the concatenation
             S.u = b(ph, B, self.fuse_tape.n_out)
             S.gmap = b(B * (no + md))
+            S.gmap_c = b(B, md)
+            if self.drop.view.get("map.feature") is not None:
+                S.enc_map_d = b(B, md)
             self.maps = b(*self.cnn_tape.in_shape)
         else:
             if self.head_tape.k_in != no:
@@ -466,6 +620,9 @@ class TrainEngine:
         for n in ("gf2", "gx2", "go2", "ga2", "gcq", "gx1", "go1", "ga1"):
             setattr(S, n, [b(ph, B, d) for _ in range(L)])
         S.gf1 = [b(ph, B, fd) for _ in range(L)]
+        S.gf2m = [b(ph, B, d) if D(f"dec{l}.drop3") else S.gf2[l] for l in range(L)]
+        S.go2m = [b(ph, B, d) if D(f"dec{l}.drop2") else S.go2[l] for l in range(L)]
+        S.go1m = [b(ph, B, d) if D(f"dec{l}.drop1") else S.go1[l] for l in range(L)]
         S.gqkv, S.gmkv = [], []
         for _ in range(L):
             S.gqkv.append(S.acc_pool[o:o + n_gqkv].view(ph, B, 3 * d))
@@ -509,18 +666,22 @@ class TrainEngine:
         """Encoder -> memory K/V -> ph decoder steps with position feedback; everything the backward needs is kept."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
         enc, dec = self.enc, self.dec
+        D = self.drop.get
+        if self.drop.active:
+            self.drop.generate()
         K.history_prepare(self.x_st, S.x0, S.pad)
-        K.gemm(S.x0, _t(enc.input_fc.weight), S.eh[0], bias=enc.input_fc.bias, addend=S.pe_enc)
+        K.gemm(S.x0, _t(enc.input_fc.weight), S.eh[0], bias=enc.input_fc.bias, addend=S.pe_enc, drop=D("enc.pe"),
+               drop_after_add=True)
         for l, lay in enumerate(enc.transformer_encoder.layers):
             sa = lay.self_attn
             K.gemm(S.eh[l], _t(sa.in_proj_weight), S.eqkv[l], bias=sa.in_proj_bias)
             qkv = S.eqkv[l].view(B, T, 3 * d)
             K.attention_fwd(qkv[:, :, 0:d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], S.eatt[l].view(B, T, d), S.eprobs[l],
-                            H, self.scale, pad=S.pad, causal=True)
-            K.gemm(S.eatt[l], _t(sa.out_proj.weight), S.etmp, bias=sa.out_proj.bias, addend=S.eh[l])
+                            H, self.scale, pad=S.pad, causal=True, pdrop=D(f"enc{l}.attn"))
+            K.gemm(S.eatt[l], _t(sa.out_proj.weight), S.etmp, bias=sa.out_proj.bias, addend=S.eh[l], drop=D(f"enc{l}.drop1"))
             K.layernorm_fwd(S.etmp, None, lay.norm1.weight, lay.norm1.bias, S.eh1[l], S.exhat1[l], S.erstd1[l])
-            K.gemm(S.eh1[l], _t(lay.linear1.weight), S.ef1[l], bias=lay.linear1.bias, relu=True)
-            K.gemm(S.ef1[l], _t(lay.linear2.weight), S.etmp, bias=lay.linear2.bias, addend=S.eh1[l])
+            K.gemm(S.eh1[l], _t(lay.linear1.weight), S.ef1[l], bias=lay.linear1.bias, relu=True, drop=D(f"enc{l}.ff"))
+            K.gemm(S.ef1[l], _t(lay.linear2.weight), S.etmp, bias=lay.linear2.bias, addend=S.eh1[l], drop=D(f"enc{l}.drop2"))
             K.layernorm_fwd(S.etmp, None, lay.norm2.weight, lay.norm2.bias, S.eh[l + 1], S.exhat2[l], S.erstd2[l])
         memory = S.eh[self.Le]
         if self.lane_mode:
@@ -544,59 +705,81 @@ class TrainEngine:
             S.pos[0].copy_(self.x_st[:, -1, 0:self.n_pos])      # start token = standardised current position
         if self.map_mode:
             S.enc_map = self.cnn_tape.forward(self.maps)
-        if not self.teacher_forced:
+            S.enc_map_used = S.enc_map
+            dm = self.drop.view.get("map.feature")
+            if dm is not None:      # F.dropout(encoded_map, 0.5, training=True), mgcvae.py:291-293
+                S.enc_map_d.copy_(S.enc_map)
+                K.dropout_apply(S.enc_map_d, dm[0], dm[1], S.enc_map_d)
+                S.enc_map_used = S.enc_map_d
+        if self.teacher_forced:     # positions = running sum of the head outputs (mgcvae.py:352,370), from pos[0] = 0
+            self._decoder_steps(0, ph)
+            R = ph * B
+            self.head_tape.forward_out(self._head_z, S.delta.view(R, self.n_pos))
+            K.cumsum_axis(S.delta.view(1, ph, B * self.n_pos), S.pos[1:].view(1, ph, B * self.n_pos), 1)
+        elif self.drop.active:
+            # With dropout the fed-back positions depend on the masks: the decode runs step by step on the stash kernels (the
+            # KV-cached recurrence, one query per agent against the keys of steps 0..s), which also IS the stash pass.
+            for s_ in range(ph):
+                self._decoder_steps(s_, s_ + 1)
+                self.head_tape.forward_out(self._head_z, S.pos[s_ + 1], addend=S.pos[s_])
+        else:
             # The autoregressive decode itself runs on the fused decoder kernels (positions only, nothing kept); with the
             # tokens known, every activation the backward needs is recomputed for all ph steps at once: causal
             # self-attention over the steps equals the KV-cached recurrence, and ph*B-row GEMMs replace ph B-row ones.
             self._ar_decode()
-        self._decoder_all_steps()
-        if self.teacher_forced:     # positions = running sum of the head outputs (mgcvae.py:352,370), from pos[0] = 0
-            R = ph * B
-            self.head_tape.forward_out(self._head_z, S.delta.view(R, self.n_pos))
-            K.cumsum_axis(S.delta.view(1, ph, B * self.n_pos), S.pos[1:].view(1, ph, B * self.n_pos), 1)
+            self._decoder_steps(0, ph)
         # loss value and dL/dpos in one pass (mgcvae.py:614-620)
         self.loss.zero_()
         K.l2_loss_bwd(S.pos[1:], self.y_st, S.G[1:], self.loss)
         return self.loss
 
-    def _decoder_all_steps(self):
-        """Decoder stack + head hidden layers for all ph steps at once on the tokens in ``S.tok`` (step-major rows
-        s*B+b), keeping every activation the backward reads.  Needs the encoder stash and ``S.mkv``."""
+    def _decoder_steps(self, s0, s1):
+        """Decoder stack + head hidden layers for steps s0..s1-1 on the tokens in ``S.tok`` (step-major rows s*B+b), keeping
+        every activation the backward reads; the keys / values of steps < s0 must already be in the stash.  (0, ph): all steps
+        at once (tokens known); (s, s+1): one step of the recurrence.  Needs the encoder stash and ``S.mkv``."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
         dec = self.dec
         layers = dec.transformer_decoder.layers
-        R = ph * B
-        f2 = lambda t: t.view(R, t.shape[-1])
-        K.gemm(f2(S.tok), _t(dec.input_fc.weight), f2(S.x[0]), bias=dec.input_fc.bias, addend=S.pe_dec)
+        R, r0, r1 = ph * B, s0 * B, s1 * B
+        f2 = lambda t: t.view(R, t.shape[-1])[r0:r1]
+        bm = lambda t: t[s0:s1].permute(1, 0, 2)          # (B, s1-s0, .) view of the step-major stash
+        D = self.drop.get
+        dr = lambda name: None if D(name) is None else (f2(D(name)[0]), D(name)[1])
+        K.gemm(f2(S.tok), _t(dec.input_fc.weight), f2(S.x[0]), bias=dec.input_fc.bias, addend=S.pe_dec[r0:r1],
+               drop=dr("dec.pe"), drop_after_add=True)
         mask_b = S.pad
         for l, lay in enumerate(layers):
             sa, ca = lay.self_attn, lay.multihead_attn
             K.gemm(f2(S.x[l]), _t(sa.in_proj_weight), f2(S.qkv[l]), bias=sa.in_proj_bias)
-            c = S.qkv[l].permute(1, 0, 2)                  # (B,ph,3d) view of the step-major stash
-            K.attention_fwd(c[:, :, 0:d], c[:, :, d:2 * d], c[:, :, 2 * d:], S.a1[l].permute(1, 0, 2), S.p1[l], H,
-                            self.scale, causal=True)
-            K.gemm(f2(S.a1[l]), _t(sa.out_proj.weight), S.tmp, bias=sa.out_proj.bias, addend=f2(S.x[l]))
-            K.layernorm_fwd(S.tmp, None, lay.norm1.weight, lay.norm1.bias, f2(S.x1[l]), f2(S.xhat1[l]), S.rstd1[l].view(R))
+            ckv = S.qkv[l][0:s1].permute(1, 0, 2)          # keys / values of steps 0..s1-1
+            pd1 = D(f"dec{l}.attn1")
+            K.attention_fwd(bm(S.qkv[l])[:, :, 0:d], ckv[:, :, d:2 * d], ckv[:, :, 2 * d:], bm(S.a1[l]), S.p1[l][s0 * ph:], H,
+                            self.scale, causal=True, causal_offset=s0, probs_strides=(ph * ph, ph),
+                            pdrop=None if pd1 is None else (pd1[0][s0 * ph:], pd1[1]))
+            tmp = S.tmp[r0:r1]
+            K.gemm(f2(S.a1[l]), _t(sa.out_proj.weight), tmp, bias=sa.out_proj.bias, addend=f2(S.x[l]), drop=dr(f"dec{l}.drop1"))
+            K.layernorm_fwd(tmp, None, lay.norm1.weight, lay.norm1.bias, f2(S.x1[l]), f2(S.xhat1[l]), S.rstd1[l].view(R)[r0:r1])
             K.gemm(f2(S.x1[l]), _t(ca.in_proj_weight[:d]), f2(S.cq[l]), bias=ca.in_proj_bias[:d])
             mkv = S.mkv[l].view(B, T, 2 * d)
-            K.attention_fwd(S.cq[l].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.a2[l].permute(1, 0, 2), S.p2[l], H,
-                            self.scale, pad=mask_b)
-            K.gemm(f2(S.a2[l]), _t(ca.out_proj.weight), S.tmp, bias=ca.out_proj.bias, addend=f2(S.x1[l]))
-            K.layernorm_fwd(S.tmp, None, lay.norm2.weight, lay.norm2.bias, f2(S.x2[l]), f2(S.xhat2[l]), S.rstd2[l].view(R))
-            K.gemm(f2(S.x2[l]), _t(lay.linear1.weight), f2(S.f1[l]), bias=lay.linear1.bias, relu=True)
-            K.gemm(f2(S.f1[l]), _t(lay.linear2.weight), S.tmp, bias=lay.linear2.bias, addend=f2(S.x2[l]))
-            K.layernorm_fwd(S.tmp, None, lay.norm3.weight, lay.norm3.bias, f2(S.x[l + 1]), f2(S.xhat3[l]),
-                            S.rstd3[l].view(R))
+            pd2 = D(f"dec{l}.attn2")
+            K.attention_fwd(bm(S.cq[l]), mkv[:, :, :d], mkv[:, :, d:], bm(S.a2[l]), S.p2[l][s0 * T:], H, self.scale, pad=mask_b,
+                            probs_strides=(ph * T, T), pdrop=None if pd2 is None else (pd2[0][s0 * T:], pd2[1]))
+            K.gemm(f2(S.a2[l]), _t(ca.out_proj.weight), tmp, bias=ca.out_proj.bias, addend=f2(S.x1[l]), drop=dr(f"dec{l}.drop2"))
+            K.layernorm_fwd(tmp, None, lay.norm2.weight, lay.norm2.bias, f2(S.x2[l]), f2(S.xhat2[l]), S.rstd2[l].view(R)[r0:r1])
+            K.gemm(f2(S.x2[l]), _t(lay.linear1.weight), f2(S.f1[l]), bias=lay.linear1.bias, relu=True, drop=dr(f"dec{l}.ff"))
+            K.gemm(f2(S.f1[l]), _t(lay.linear2.weight), tmp, bias=lay.linear2.bias, addend=f2(S.x2[l]), drop=dr(f"dec{l}.drop3"))
+            K.layernorm_fwd(tmp, None, lay.norm3.weight, lay.norm3.bias, f2(S.x[l + 1]), f2(S.xhat3[l]),
+                            S.rstd3[l].view(R)[r0:r1])
         no = self.n_out
         if self.map_mode:
             hcat = f2(S.hcat)
             K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), hcat[:, :no], bias=dec.output_fc.bias)
-            S.hcat[:, :, no:].copy_(S.enc_map.unsqueeze(0).expand(ph, B, -1))
-            self.fuse_tape.forward_out(self.fuse_tape.forward_hidden(hcat), f2(S.u))
-            self._head_z = self.head_tape.forward_hidden(f2(S.u))
+            S.hcat[s0:s1, :, no:].copy_(S.enc_map_used.unsqueeze(0).expand(s1 - s0, B, -1))
+            self.fuse_tape.forward_out(self.fuse_tape.forward_hidden(hcat, (r0, r1)), f2(S.u))
+            self._head_z = self.head_tape.forward_hidden(f2(S.u), (r0, r1))
         else:
             K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), f2(S.ho), bias=dec.output_fc.bias)
-            self._head_z = self.head_tape.forward_hidden(f2(S.ho))
+            self._head_z = self.head_tape.forward_hidden(f2(S.ho), (r0, r1))
 
     def _ar_decode(self):
         """pos[1:] <- the 12-step autoregressive decode of the current parameters (mgcvae.py:375-449) on the fused
@@ -645,25 +828,36 @@ class TrainEngine:
         else:
             K.ln_param_grads(dy, xhat, self.g(ln.weight), self.g(ln.bias))
 
-    def _ln_gemm(self, dy, xhat, rstd, gamma, dx, w, out, **kw):
-        """dx = LayerNorm backward of dy; out = epi(dx @ w).  One kernel when the row-block GEMM takes the shape (the
-        per-step sweep at B <= 256), two otherwise."""
+    def _ln_gemm(self, dy, xhat, rstd, gamma, dx, w, out, ln_drop=None, **kw):
+        """dx = LayerNorm backward of dy; out = epi(dx' @ w), dx' = dx or, with ``ln_drop=(keep, scale, dxm)``, dxm =
+        keep*scale*dx.  One kernel when the row-block GEMM takes the shape (the per-step sweep at B <= 256), two otherwise."""
         M, Kd = dy.shape
         if M <= 256 and Kd % 16 == 0 and Kd <= 768:
-            K.gemm(dy, w, out, ln_bwd=(xhat, rstd, gamma, dx), **kw)
+            K.gemm(dy, w, out, ln_bwd=(xhat, rstd, gamma, dx), ln_drop=ln_drop, **kw)
         else:
-            K.layernorm_bwd(dy, xhat, rstd, gamma, dx)
-            K.gemm(dx, w, out, **kw)
+            K.layernorm_bwd(dy, xhat, rstd, gamma, dx, drop=ln_drop)
+            K.gemm(dx if ln_drop is None else ln_drop[2], w, out, **kw)
 
-    def _ln_gemm_attn(self, dy, xhat, rstd, gamma, dx, w, d_o, q, k, v, probs, dq, dk, dv, pstrides):
-        """dx = LayerNorm backward of dy; d_o = dx @ w (out_proj's input gradient); attention backward of one query per
-        agent from d_o.  One kernel when the shapes allow (d_o then never leaves the chip), else the separate ones."""
+    def _ln_gemm_attn(self, dy, xhat, rstd, gamma, dx, w, d_o, q, k, v, probs, dq, dk, dv, pstrides, ln_drop=None, pdrop=None):
+        """dx = LayerNorm backward of dy; d_o = dx' @ w (out_proj's input gradient, dx' as in ``_ln_gemm``); attention backward
+        of one query per agent from d_o.  One kernel when the shapes allow (d_o then never leaves the chip), else the separate
+        ones."""
         if K.gemm_attention_bwd_ok(dy, self.H, k.shape[1], self.dh):
             K.gemm_attention_bwd(dy, w, q, k, v, probs, dq, dk, dv, self.H, self.scale, ln_bwd=(xhat, rstd, gamma, dx),
-                                 probs_strides=pstrides)
+                                 probs_strides=pstrides, ln_drop=ln_drop, pdrop=pdrop)
             return
-        self._ln_gemm(dy, xhat, rstd, gamma, dx, w, d_o)
-        K.attention_bwd(q, k, v, probs, d_o.view(dy.shape[0], 1, -1), dq, dk, dv, self.H, self.scale, probs_strides=pstrides)
+        self._ln_gemm(dy, xhat, rstd, gamma, dx, w, d_o, ln_drop=ln_drop)
+        K.attention_bwd(q, k, v, probs, d_o.view(dy.shape[0], 1, -1), dq, dk, dv, self.H, self.scale, probs_strides=pstrides,
+                        pdrop=pdrop)
+
+    def _site(self, name, s, dxm):
+        """ln_drop triple of decoder site ``name`` at step ``s`` (None when the site is not dropped)."""
+        v = self.drop.get(name, s)
+        return None if v is None else (v[0], v[1], dxm)
+
+    def _psite(self, name, off):
+        v = self.drop.get(name)
+        return None if v is None else (v[0][off:], v[1])
 
     def backward(self):
         """Reverse-time sweep.  ``forward`` must have run; ``S.G[1:]`` holds dL/dpos from the loss kernel."""
@@ -682,14 +876,17 @@ class TrainEngine:
                 lay = layers[l]
                 sa, ca = lay.self_attn, lay.multihead_attn
                 # (each LayerNorm backward rides in the operand load of the GEMM that consumes it)
+                dff = self.drop.get(f"dec{l}.ff")
                 self._ln_gemm(S.gx[l + 1][s], S.xhat3[l][s], S.rstd3[l][s], lay.norm3.weight, S.gf2[l][s],
-                              lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s])
+                              lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s], mask_scale=dff[1] if dff else 0.0,
+                              ln_drop=self._site(f"dec{l}.drop3", s, S.gf2m[l][s]))
                 K.gemm(S.gf1[l][s], lay.linear1.weight, S.gx2[l][s], addend=S.gf2[l][s])
                 mkv, gmkv = S.mkv[l].view(B, T, 2 * d), S.gmkv[l].view(B, T, 2 * d)
                 self._ln_gemm_attn(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s],
                                    ca.out_proj.weight, S.ga2[l][s],
                                    S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s * T:],
-                                   S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d], gmkv[:, :, d:], (ph * T, T))
+                                   S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d], gmkv[:, :, d:], (ph * T, T),
+                                   ln_drop=self._site(f"dec{l}.drop2", s, S.go2m[l][s]), pdrop=self._psite(f"dec{l}.attn2", s * T))
                 K.gemm(S.gcq[l][s], ca.in_proj_weight[:d], S.gx1[l][s], addend=S.go2[l][s])
                 c, gc = S.qkv[l], S.gqkv[l]
                 self._ln_gemm_attn(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s],
@@ -697,8 +894,11 @@ class TrainEngine:
                                    c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
                                    c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s * ph:],
                                    gc[s:s + 1, :, 0:d].permute(1, 0, 2), gc[0:s + 1, :, d:2 * d].permute(1, 0, 2),
-                                   gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), (ph * ph, ph))
-                K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s])
+                                   gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), (ph * ph, ph),
+                                   ln_drop=self._site(f"dec{l}.drop1", s, S.go1m[l][s]), pdrop=self._psite(f"dec{l}.attn1", s * ph))
+                # (layer 0: x[0] = dropout(embedding + pe); the gradient that leaves the sweep is the one at the embedding)
+                K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s],
+                       drop=self.drop.get("dec.pe", s) if l == 0 else None, drop_after_add=True)
             if s > 0 and self.teacher_forced:      # G[s] = dL/dpos[s] + residual (cumsum) path; tokens are constants
                 K.add_inplace(S.G[s], S.G[s + 1])
             elif s > 0:    # G[s] = dL/dpos[s] (already there) + residual path + embedding path
@@ -711,15 +911,15 @@ class TrainEngine:
         for l, lay in enumerate(layers):
             sa, ca = lay.self_attn, lay.multihead_attn
             self._wgrad(f2(S.gqkv[l]), f2(S.x[l]), sa.in_proj_weight, sa.in_proj_bias)
-            self._wgrad(f2(S.go1[l]), f2(S.a1[l]), sa.out_proj.weight, sa.out_proj.bias)
+            self._wgrad(f2(S.go1m[l]), f2(S.a1[l]), sa.out_proj.weight, sa.out_proj.bias)
             self._ln_grad(f2(S.gx1[l]), f2(S.xhat1[l]), lay.norm1)
             gw, gb = self.g(ca.in_proj_weight), self.g(ca.in_proj_bias)
             self._wgrad_rows(f2(S.gcq[l]), f2(S.x1[l]), gw[:d], gb[:d])
             self._wgrad_rows(S.gmkv[l], memory, gw[d:], gb[d:])
-            self._wgrad(f2(S.go2[l]), f2(S.a2[l]), ca.out_proj.weight, ca.out_proj.bias)
+            self._wgrad(f2(S.go2m[l]), f2(S.a2[l]), ca.out_proj.weight, ca.out_proj.bias)
             self._ln_grad(f2(S.gx2[l]), f2(S.xhat2[l]), lay.norm2)
             self._wgrad(f2(S.gf1[l]), f2(S.x2[l]), lay.linear1.weight, lay.linear1.bias)
-            self._wgrad(f2(S.gf2[l]), f2(S.f1[l]), lay.linear2.weight, lay.linear2.bias)
+            self._wgrad(f2(S.gf2m[l]), f2(S.f1[l]), lay.linear2.weight, lay.linear2.bias)
             self._ln_grad(f2(S.gx[l + 1]), f2(S.xhat3[l]), lay.norm3)
         self._wgrad(f2(S.gho), f2(S.x[L]), dec.output_fc.weight, dec.output_fc.bias)
         if self.map_mode:
@@ -727,7 +927,13 @@ class TrainEngine:
             self.fuse_tape.wgrads(self, f2(S.hcat), f2(self.head_tape.gin))
             # d encoded_map = sum over the steps of the concatenation's last columns, then back through the CNN
             K.colsum(self.fuse_tape.gin.view(ph, B * self.fuse_tape.k_in), S.gmap)
-            self.cnn_tape.backward(self, S.gmap.view(B, self.fuse_tape.k_in)[:, self.n_out:])
+            gm = S.gmap.view(B, self.fuse_tape.k_in)[:, self.n_out:]
+            dm = self.drop.view.get("map.feature")
+            if dm is not None:
+                S.gmap_c.copy_(gm)
+                K.dropout_apply(S.gmap_c, dm[0], dm[1], S.gmap_c)
+                gm = S.gmap_c
+            self.cnn_tape.backward(self, gm)
         else:
             self.head_tape.wgrads(self, f2(S.ho), f2(S.G[1:]))
         # ---- encoder: d memory = sum over decoder layers of d(memory K/V) W_kv
@@ -745,20 +951,25 @@ class TrainEngine:
         for l in range(self.Le - 1, -1, -1):
             lay = enc.transformer_encoder.layers[l]
             sa = lay.self_attn
-            K.layernorm_bwd(S.geh[l + 1], S.exhat2[l], S.erstd2[l], lay.norm2.weight, S.gef2[l])
-            K.gemm(S.gef2[l], lay.linear2.weight, S.gef1[l], mask=S.ef1[l])
+            De = self.drop.get
+            d2, d1, dff = De(f"enc{l}.drop2"), De(f"enc{l}.drop1"), De(f"enc{l}.ff")
+            K.layernorm_bwd(S.geh[l + 1], S.exhat2[l], S.erstd2[l], lay.norm2.weight, S.gef2[l],
+                            drop=(d2[0], d2[1], S.gef2m[l]) if d2 else None)
+            K.gemm(S.gef2m[l], lay.linear2.weight, S.gef1[l], mask=S.ef1[l], mask_scale=dff[1] if dff else 0.0)
             K.gemm(S.gef1[l], lay.linear1.weight, S.geh1[l], addend=S.gef2[l])
-            K.layernorm_bwd(S.geh1[l], S.exhat1[l], S.erstd1[l], lay.norm1.weight, S.geo1[l])
-            K.gemm(S.geo1[l], sa.out_proj.weight, S.geatt[l])
+            K.layernorm_bwd(S.geh1[l], S.exhat1[l], S.erstd1[l], lay.norm1.weight, S.geo1[l],
+                            drop=(d1[0], d1[1], S.geo1m[l]) if d1 else None)
+            K.gemm(S.geo1m[l], sa.out_proj.weight, S.geatt[l])
             qkv, gq = S.eqkv[l].view(B, T, 3 * d), S.geqkv[l].view(B, T, 3 * d)
             K.attention_bwd(qkv[:, :, 0:d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], S.eprobs[l], S.geatt[l].view(B, T, d),
-                            gq[:, :, 0:d], gq[:, :, d:2 * d], gq[:, :, 2 * d:], H, self.scale)
-            K.gemm(S.geqkv[l], sa.in_proj_weight, S.geh[l], addend=S.geo1[l])
-            self._wgrad(S.gef2[l], S.ef1[l], lay.linear2.weight, lay.linear2.bias)
+                            gq[:, :, 0:d], gq[:, :, d:2 * d], gq[:, :, 2 * d:], H, self.scale, pdrop=De(f"enc{l}.attn"))
+            K.gemm(S.geqkv[l], sa.in_proj_weight, S.geh[l], addend=S.geo1[l], drop=De("enc.pe") if l == 0 else None,
+                   drop_after_add=True)
+            self._wgrad(S.gef2m[l], S.ef1[l], lay.linear2.weight, lay.linear2.bias)
             self._ln_grad(S.geh[l + 1], S.exhat2[l], lay.norm2)
             self._wgrad(S.gef1[l], S.eh1[l], lay.linear1.weight, lay.linear1.bias)
             self._ln_grad(S.geh1[l], S.exhat1[l], lay.norm1)
-            self._wgrad(S.geo1[l], S.eatt[l], sa.out_proj.weight, sa.out_proj.bias)
+            self._wgrad(S.geo1m[l], S.eatt[l], sa.out_proj.weight, sa.out_proj.bias)
             self._wgrad(S.geqkv[l], S.eh[l], sa.in_proj_weight, sa.in_proj_bias)
         self._wgrad(S.geh[0], S.x0, enc.input_fc.weight, enc.input_fc.bias)
         self._sum_split_parts()
@@ -787,10 +998,28 @@ class _TrainLossFn(torch.autograd.Function):
         return (None,) + tuple(eng.g(p) for _, p in eng.named_params)
 
 
+def disable_dropout(model):
+    """Set every dropout probability of ``model`` (a MultimodalGenerativeCVAE) to 0 -- nn.Dropout.p, nn.MultiheadAttention.dropout
+    and the map-feature probability in the hyperparameters -- the configuration training parity is defined on (SURVEY.md
+    section 0.5).  Engines read the probabilities when they are built: call this before the first training step."""
+    for mod in model.node_modules.values():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, torch.nn.MultiheadAttention):
+                m.dropout = 0.0
+    cp = model.hyperparams.get("map_encoder", {}).get("cnn_param")
+    if cp is not None:
+        cp["dropout"] = 0.0
+    model.__dict__.pop("_train_engines", None)
+    return model
+
+
 def train_loss_with_graph(model, x_st, y_st, ph, teacher_forced=False, maps=None, lanes=None):
-    """``MultimodalGenerativeCVAE.train_loss`` body (Basic / Map_encoding_CNN / Lane_encoding_CNN): a scalar with autograd."""
+    """``MultimodalGenerativeCVAE.train_loss`` body (Basic / Map_encoding_CNN / Lane_encoding_CNN): a scalar with autograd.
+    Dropout as the modules say (training mode, p > 0) at the time the engine of this shape is first built."""
     B, T, _ = x_st.shape
-    key = (B, T, ph, bool(teacher_forced))
+    key = (B, T, ph, bool(teacher_forced), bool(model._m("node_history_encoder").training))
     cache = model.__dict__.setdefault("_train_engines", {})
     eng = cache.get(key)
     if eng is None:
@@ -807,10 +1036,15 @@ class Trainer:
     0.01), second parameter group 'map_encoder' at lr 8e-4, ``clip_grad_value_(hp.grad_clip)`` on the averaged
     gradient, ExponentialLR(hp.learning_decay_rate) stepped once per batch."""
 
-    def __init__(self, model, B, T, ph, use_graph=True, process_group=None, distributed=True, always_reduce=False):
+    def __init__(self, model, B, T, ph, use_graph=True, process_group=None, distributed=True, always_reduce=False,
+                 dropout=None, seed=0):
+        """``dropout``: None = as the modules say (training mode and p > 0, like torch), False = the dropout-free graph.
+        ``seed``: of the dropout masks; data-parallel ranks must pass different seeds (or masks repeat across shards)."""
         import torch.distributed as dist
         hp = model.hyperparams
-        self.engine = TrainEngine(model, B, T, ph)
+        if dropout is None and distributed and dist.is_available() and dist.is_initialized():
+            seed = int(seed) + 7919 * dist.get_rank(process_group)
+        self.engine = TrainEngine(model, B, T, ph, dropout=dropout, seed=seed)
         self.hp = hp
         self.world = 1
         if distributed and dist.is_available() and dist.is_initialized():

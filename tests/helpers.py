@@ -14,6 +14,12 @@ TINY_TR = {"nlayers": 2, "nhead": 2, "in_dim": 32, "fdim": 64, "output_size": 32
 MODES = ("basic", "map_cnn", "lane_cnn")
 
 
+def no_dropout(model):
+    """The goldens were generated with every dropout probability forced to 0: same here."""
+    from multimodal_transformer_amd.training import disable_dropout
+    return disable_dropout(model)
+
+
 def load_golden(tag):
     z = np.load(os.path.join(GOLDEN, tag + ".npz"))
     with open(os.path.join(GOLDEN, tag + ".json")) as f:

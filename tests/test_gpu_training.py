@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import fake_kernels as F
+import helpers
 from helpers import batch_for, check_post_step, hp_for, load_golden, rel_err, set_weights
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +27,7 @@ def _model(hp, dev, autoregressive=True):
     from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
     hp["autoregressive"] = autoregressive
     reg = ModelRegistrar("/tmp", dev)
-    return MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, []), reg
+    return helpers.no_dropout(MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, [])), reg
 
 
 def _rand(*shape, seed=0, scale=1.0):

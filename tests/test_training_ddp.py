@@ -42,12 +42,12 @@ def _worker(rank, world, port, out_dir):
     batches = [make_batch(B, 4, 3, seed=30 + i) for i in range(2)]
     shard = slice(rank * B // world, (rank + 1) * B // world)
     model, reg = build()
-    tr = training.Trainer(model, B // world, 5, 3, use_graph=False)
+    tr = training.Trainer(model, B // world, 5, 3, use_graph=False, dropout=False)
     assert tr.world == world
     for b in batches:
         tr.step(torch.from_numpy(b["x_st"][shard]), torch.from_numpy(b["y_st"][shard]))
     ref_model, ref_reg = build()
-    ref = training.Trainer(ref_model, B, 5, 3, use_graph=False, distributed=False)
+    ref = training.Trainer(ref_model, B, 5, 3, use_graph=False, distributed=False, dropout=False)
     for b in batches:
         ref.step(torch.from_numpy(b["x_st"]), torch.from_numpy(b["y_st"]))
     worst = 0.0

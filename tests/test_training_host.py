@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import fake_kernels
+import helpers
 from helpers import batch_for, check_post_step, hp_for, load_golden, rel_err, set_weights
 
 GRAD_TOL = 1e-4
@@ -20,7 +21,7 @@ class _Env:
 def _model(hp):
     from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
     reg = ModelRegistrar("/tmp", "cpu")
-    return MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, "cpu", []), reg
+    return helpers.no_dropout(MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, "cpu", [])), reg
 
 
 def _tiny_engine(monkeypatch):
