@@ -91,16 +91,18 @@ class _MlpTape:
     def forward_out(self, z, out, addend=None):
         K.gemm(z, _t(self.out.weight), out, bias=self.out.bias, addend=addend)
 
-    def backward_step(self, s, gout):
+    def backward_step(self, s, gout, rows=None):
+        """``rows=(b0, b1)``: only these rows of step s (gout holds them): the sweep runs per agent range."""
+        b0, b1 = rows if rows is not None else (0, self.B)
         gin, w = gout, self.out.weight
         for i in range(len(self.hidden) - 1, -1, -1):
             lin, ln = self.hidden[i]
-            K.gemm(gin, w, self.ghu[i][s])
-            K.layernorm_bwd(self.ghu[i][s], self.hxhat[i][s], self.hrstd[i][s], ln.weight, self.ghz[i][s], y_relu=self.hu[i][s],
-                            dy_masked=self.ghum[i][s])
-            gin, w = self.ghz[i][s], lin.weight
-        K.gemm(gin, w, self.gin[s])
-        return self.gin[s]
+            K.gemm(gin, w, self.ghu[i][s][b0:b1])
+            K.layernorm_bwd(self.ghu[i][s][b0:b1], self.hxhat[i][s][b0:b1], self.hrstd[i][s][b0:b1], ln.weight,
+                            self.ghz[i][s][b0:b1], y_relu=self.hu[i][s][b0:b1], dy_masked=self.ghum[i][s][b0:b1])
+            gin, w = self.ghz[i][s][b0:b1], lin.weight
+        K.gemm(gin, w, self.gin[s][b0:b1])
+        return self.gin[s][b0:b1]
 
     def wgrads(self, eng, zin_all, gout_all):
         z = zin_all
@@ -859,6 +861,71 @@ class TrainEngine:
         v = self.drop.get(name)
         return None if v is None else (v[0][off:], v[1])
 
+    def _sweep_chunks(self):
+        """Agent ranges of the reverse-time sweep: multiples of 16 agents (the row-block GEMM's tile), at most ``sweep_ways``."""
+        B = self.B
+        ways = int(getattr(self, "sweep_ways", 1))
+        if not torch.device(self.device).type == "cuda" or ways <= 1 or B < 64:
+            return [(0, B)]
+        n = max(1, min(ways, B // 32))
+        per = ((B + n - 1) // n + 15) // 16 * 16
+        return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+
+    def _sweep_streams(self, n):
+        st = self.__dict__.setdefault("_sweep_st", [])
+        while len(st) < n:
+            st.append(torch.cuda.Stream(self.device))
+        return st[:n]
+
+    def _sweep(self, b0, b1):
+        """Reverse-time sweep over the decoder steps for agents b0..b1-1."""
+        S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
+        dec = self.dec
+        layers = dec.transformer_decoder.layers
+        L = self.Ld
+        r = lambda t, s_: t[s_][b0:b1]                               # rows of step s_ of a step-major (ph, B, .) stash
+        bq = lambda t, s_, c0, c1: t[s_:s_ + 1, b0:b1, c0:c1].permute(1, 0, 2)     # (agents, 1, .) query view
+        bk = lambda t, s_, c0, c1: t[0:s_ + 1, b0:b1, c0:c1].permute(1, 0, 2)      # (agents, s_+1, .) key / value view
+        site = lambda name, s_, dxm: None if self.drop.get(name) is None else \
+            (self.drop.get(name)[0][s_][b0:b1], self.drop.get(name)[1], dxm)
+        for s in range(ph - 1, -1, -1):
+            # head: pos[s+1] = pos[s] + out(relu(LN(lin(.)))...)   (MLP.py:12-24, mgcvae.py:445)
+            gin = self.head_tape.backward_step(s, r(S.G, s + 1), (b0, b1))
+            if self.map_mode:
+                self.fuse_tape.backward_step(s, gin, (b0, b1))          # -> gradient at cat[output_fc(x), encoded_map]
+            K.gemm(r(S.gho, s), dec.output_fc.weight, r(S.gx[L], s))
+            for l in range(L - 1, -1, -1):
+                lay = layers[l]
+                sa, ca = lay.self_attn, lay.multihead_attn
+                # (each LayerNorm backward rides in the operand load of the GEMM that consumes it)
+                dff = self.drop.get(f"dec{l}.ff")
+                self._ln_gemm(r(S.gx[l + 1], s), r(S.xhat3[l], s), r(S.rstd3[l], s), lay.norm3.weight, r(S.gf2[l], s),
+                              lay.linear2.weight, r(S.gf1[l], s), mask=r(S.f1[l], s), mask_scale=dff[1] if dff else 0.0,
+                              ln_drop=site(f"dec{l}.drop3", s, r(S.gf2m[l], s)))
+                K.gemm(r(S.gf1[l], s), lay.linear1.weight, r(S.gx2[l], s), addend=r(S.gf2[l], s))
+                mkv, gmkv = S.mkv[l].view(B, T, 2 * d)[b0:b1], S.gmkv[l].view(B, T, 2 * d)[b0:b1]
+                o2, o1 = b0 * H * ph * T + s * T, b0 * H * ph * ph + s * ph
+                self._ln_gemm_attn(r(S.gx2[l], s), r(S.xhat2[l], s), r(S.rstd2[l], s), lay.norm2.weight, r(S.go2[l], s),
+                                   ca.out_proj.weight, r(S.ga2[l], s),
+                                   bq(S.cq[l], s, 0, d), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][o2:],
+                                   bq(S.gcq[l], s, 0, d), gmkv[:, :, :d], gmkv[:, :, d:], (ph * T, T),
+                                   ln_drop=site(f"dec{l}.drop2", s, r(S.go2m[l], s)), pdrop=self._psite(f"dec{l}.attn2", o2))
+                K.gemm(r(S.gcq[l], s), ca.in_proj_weight[:d], r(S.gx1[l], s), addend=r(S.go2[l], s))
+                c, gc = S.qkv[l], S.gqkv[l]
+                self._ln_gemm_attn(r(S.gx1[l], s), r(S.xhat1[l], s), r(S.rstd1[l], s), lay.norm1.weight, r(S.go1[l], s),
+                                   sa.out_proj.weight, r(S.ga1[l], s),
+                                   bq(c, s, 0, d), bk(c, s, d, 2 * d), bk(c, s, 2 * d, 3 * d), S.p1[l][o1:],
+                                   bq(gc, s, 0, d), bk(gc, s, d, 2 * d), bk(gc, s, 2 * d, 3 * d), (ph * ph, ph),
+                                   ln_drop=site(f"dec{l}.drop1", s, r(S.go1m[l], s)), pdrop=self._psite(f"dec{l}.attn1", o1))
+                # (layer 0: x[0] = dropout(embedding + pe); the gradient that leaves the sweep is the one at the embedding)
+                pe = self.drop.get("dec.pe") if l == 0 else None
+                K.gemm(r(gc, s), sa.in_proj_weight, r(S.gx[l], s), addend=r(S.go1[l], s),
+                       drop=None if pe is None else (pe[0][s][b0:b1], pe[1]), drop_after_add=True)
+            if s > 0 and self.teacher_forced:      # G[s] = dL/dpos[s] + residual (cumsum) path; tokens are constants
+                K.add_inplace(r(S.G, s), r(S.G, s + 1))
+            elif s > 0:    # G[s] = dL/dpos[s] (already there) + residual path + embedding path
+                K.gemm(r(S.gx[0], s), dec.input_fc.weight, r(S.G, s), addend=r(S.G, s + 1), accumulate=True)
+
     def backward(self):
         """Reverse-time sweep.  ``forward`` must have run; ``S.G[1:]`` holds dL/dpos from the loss kernel."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
@@ -866,43 +933,21 @@ class TrainEngine:
         layers = dec.transformer_decoder.layers
         L = self.Ld
         S.acc_pool.zero_()
-        for s in range(ph - 1, -1, -1):
-            # head: pos[s+1] = pos[s] + out(relu(LN(lin(.)))...)   (MLP.py:12-24, mgcvae.py:445)
-            gin = self.head_tape.backward_step(s, S.G[s + 1])
-            if self.map_mode:
-                self.fuse_tape.backward_step(s, gin)          # -> gradient at cat[output_fc(x), encoded_map]
-            K.gemm(S.gho[s], dec.output_fc.weight, S.gx[L][s])
-            for l in range(L - 1, -1, -1):
-                lay = layers[l]
-                sa, ca = lay.self_attn, lay.multihead_attn
-                # (each LayerNorm backward rides in the operand load of the GEMM that consumes it)
-                dff = self.drop.get(f"dec{l}.ff")
-                self._ln_gemm(S.gx[l + 1][s], S.xhat3[l][s], S.rstd3[l][s], lay.norm3.weight, S.gf2[l][s],
-                              lay.linear2.weight, S.gf1[l][s], mask=S.f1[l][s], mask_scale=dff[1] if dff else 0.0,
-                              ln_drop=self._site(f"dec{l}.drop3", s, S.gf2m[l][s]))
-                K.gemm(S.gf1[l][s], lay.linear1.weight, S.gx2[l][s], addend=S.gf2[l][s])
-                mkv, gmkv = S.mkv[l].view(B, T, 2 * d), S.gmkv[l].view(B, T, 2 * d)
-                self._ln_gemm_attn(S.gx2[l][s], S.xhat2[l][s], S.rstd2[l][s], lay.norm2.weight, S.go2[l][s],
-                                   ca.out_proj.weight, S.ga2[l][s],
-                                   S.cq[l][s:s + 1].permute(1, 0, 2), mkv[:, :, :d], mkv[:, :, d:], S.p2[l][s * T:],
-                                   S.gcq[l][s:s + 1].permute(1, 0, 2), gmkv[:, :, :d], gmkv[:, :, d:], (ph * T, T),
-                                   ln_drop=self._site(f"dec{l}.drop2", s, S.go2m[l][s]), pdrop=self._psite(f"dec{l}.attn2", s * T))
-                K.gemm(S.gcq[l][s], ca.in_proj_weight[:d], S.gx1[l][s], addend=S.go2[l][s])
-                c, gc = S.qkv[l], S.gqkv[l]
-                self._ln_gemm_attn(S.gx1[l][s], S.xhat1[l][s], S.rstd1[l][s], lay.norm1.weight, S.go1[l][s],
-                                   sa.out_proj.weight, S.ga1[l][s],
-                                   c[s:s + 1, :, 0:d].permute(1, 0, 2), c[0:s + 1, :, d:2 * d].permute(1, 0, 2),
-                                   c[0:s + 1, :, 2 * d:].permute(1, 0, 2), S.p1[l][s * ph:],
-                                   gc[s:s + 1, :, 0:d].permute(1, 0, 2), gc[0:s + 1, :, d:2 * d].permute(1, 0, 2),
-                                   gc[0:s + 1, :, 2 * d:].permute(1, 0, 2), (ph * ph, ph),
-                                   ln_drop=self._site(f"dec{l}.drop1", s, S.go1m[l][s]), pdrop=self._psite(f"dec{l}.attn1", s * ph))
-                # (layer 0: x[0] = dropout(embedding + pe); the gradient that leaves the sweep is the one at the embedding)
-                K.gemm(gc[s], sa.in_proj_weight, S.gx[l][s], addend=S.go1[l][s],
-                       drop=self.drop.get("dec.pe", s) if l == 0 else None, drop_after_add=True)
-            if s > 0 and self.teacher_forced:      # G[s] = dL/dpos[s] + residual (cumsum) path; tokens are constants
-                K.add_inplace(S.G[s], S.G[s + 1])
-            elif s > 0:    # G[s] = dL/dpos[s] (already there) + residual path + embedding path
-                K.gemm(S.gx[0][s], dec.input_fc.weight, S.G[s], addend=S.G[s + 1], accumulate=True)
+        # The sweep is a chain of ~6 small dependent kernels per (step, layer): latency, not throughput.  Agents are independent
+        # of each other in it, so it can be cut into agent ranges on parallel streams (``sweep_ways`` > 1) -- measured on MI355X
+        # inside the captured graph: 7.02 ms (1 way) / 7.76 (2) / 8.28 (4) per step at B = 128: every range's chain is as long
+        # as the whole batch's (the kernels already spread the agents over workgroups), so the default is one range.
+        chunks = self._sweep_chunks()
+        if len(chunks) == 1:
+            self._sweep(0, B)
+        else:
+            cur = torch.cuda.current_stream(self.device)
+            for (b0, b1), st in zip(chunks, self._sweep_streams(len(chunks))):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    self._sweep(b0, b1)
+            for st in self._sweep_streams(len(chunks)):
+                cur.wait_stream(st)
         # ---- deferred decoder weight gradients: one GEMM per Linear over all ph*B rows
         R = ph * B
         f2 = lambda t: t.view(R, t.shape[-1])
