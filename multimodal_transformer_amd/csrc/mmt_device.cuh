@@ -79,7 +79,10 @@ __device__ __forceinline__ void wload(WRegs &r, const f32x4 *W4, int K16, int N1
 // layer: the first group of the next linear is requested before this one's last MFMAs issue, so the
 // L2/Infinity-Cache latency hides behind the epilogue, the barrier and the LayerNorm/attention phase.
 //   PRE: `pre` already holds this linear's first group (the previous call was given it as `next`).
-template <int MB, bool PRE, class Epi>
+//   XR: one more row, X[16*MB], is multiplied on the VALU from the very weight registers the MFMAs use (lane (j, q) holds
+//   W[16s + j][16c + 4q .. +3]: four FMAs per weight quad, the four q's summed across the lane groups at the flush).  A 17th
+//   row (the ViT's cls token) then costs 4 VALU FMAs per weight quad instead of a second, 15/16 empty MFMA row tile.
+template <int MB, bool PRE, class Epi, bool XR = false>
 __device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx, const float *__restrict__ Wp,
                                             int K16, int N16, Epi epi, WRegs &pre, NextLin next) {
   const int lane = lane_id();
@@ -91,10 +94,16 @@ __device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx
   const bool do_next = next.w != nullptr && fast_geom(next.K16);
   const int nfirst = min(first, max(next.N16 - 1, 0));
   f32x4 acc[WSL][MB];
+  float xacc[XR ? WSL : 1];
+  const float *xextra = X + MB * 16 * ldx + (lane >> 4) * 4;
 #pragma unroll
   for (int s = 0; s < WSL; ++s)
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (XR) {
+#pragma unroll
+    for (int s = 0; s < WSL; ++s) xacc[s] = 0.f;
+  }
 
   // Epilogue operands (bias, residual) are requested before the last MFMAs of a slab set so that the
   // flush itself is add + ds_write with nothing to wait for.
@@ -115,6 +124,13 @@ __device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx
       }
 #pragma unroll
       for (int m = 0; m < MB; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (XR) {
+        float v = xacc[s];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (s0 + s < N16 && lane < 16) epi.store_row(MB * 16, (s0 + s) * 16 + lane, v, pb[s]);
+        xacc[s] = 0.f;
+      }
     }
   };
 
@@ -156,6 +172,13 @@ __device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx
 #pragma unroll
             for (int m = 0; m < MB; ++m)
               acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][e], cur.w[s][u][e], acc[s][m], 0, 0, 0);
+        if constexpr (XR) {
+          const f32x4 xe = *reinterpret_cast<const f32x4 *>(xextra + (kg * WU + u) * 16);
+#pragma unroll
+          for (int s = 0; s < WSL; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xacc[s] = fmaf(xe[e], cur.w[s][u][e], xacc[s]);
+        }
       }
       if (kg == gps - 1) flush(first + set * nw * WSL);
       cur = nxt;
@@ -182,6 +205,13 @@ __device__ __forceinline__ void tile_linear(const float *__restrict__ X, int ldx
 #pragma unroll
             for (int m = 0; m < MB; ++m)
               acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[m][e], wv[s][e], acc[s][m], 0, 0, 0);
+        if constexpr (XR) {
+          const f32x4 xe = *reinterpret_cast<const f32x4 *>(xextra + c * 16);
+#pragma unroll
+          for (int s = 0; s < WSL; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xacc[s] = fmaf(xe[e], wv[s][e], xacc[s]);
+        }
       }
       flush(s0);
     }
@@ -223,7 +253,26 @@ struct LdsEpi {
       Y[r * ldy + c] = v;
     }
   }
+  // the extra (VALU) row of tile_linear<.., XR = true>: lane's column c, bias already in p.b
+  template <int MB>
+  __device__ __forceinline__ void store_row(int r, int c, float v, const Pre<MB> &p) const {
+    if (c < n) {
+      v += p.b;
+      if (MODE == EPI_RELU) v = fmaxf(v, 0.f);
+      if (MODE == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+      if (MODE == EPI_ADD) v += Y[r * ldy + c];
+      Y[r * ldy + c] = v;
+    }
+  }
 };
+
+// Y[0..16*MB] = the MFMA rows, Y[16*MB] = one more row on the VALU (tile_linear's XR form)
+template <int MB, int MODE>
+__device__ __forceinline__ void linear_to_lds_xrow(const float *X, int ldx, const mmt_linear &L, float *Y, int ldy) {
+  LdsEpi<MODE> epi{L.b, Y, L.n, ldy};
+  WRegs scratch;
+  tile_linear<MB, false, LdsEpi<MODE>, true>(X, ldx, L.w, round16(L.k) >> 4, round16(L.n) >> 4, epi, scratch, no_next());
+}
 
 template <int MB, int MODE, bool PRE = false>
 __device__ __forceinline__ void linear_to_lds(const float *X, int ldx, const mmt_linear &L, float *Y, int ldy,

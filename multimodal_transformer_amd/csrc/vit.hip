@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 int mmt_set_error(int code, const char *fmt, ...);   // transformer.hip
 
@@ -22,20 +23,30 @@ struct VitLaunch {
   int B, ntok, npatch_side, ldx, lds_scr, patch_dim;
 };
 
-template <int DH>
+// CLS16 (exactly 16 patches, the shipped 100 / 25 geometry): the patches own rows 0..15 = ONE MFMA row tile, the cls token sits in
+// row 16 and goes through every linear on the VALU (tile_linear's XR form) instead of dragging a second row tile that is 15/16
+// padding through the matrix cores.  Otherwise token t is row t of a two-tile block.
+template <int MB, int MODE, bool CLS16>
+__device__ __forceinline__ void vit_linear(const float *X, int ldx, const mmt_linear &L, float *Y, int ldy) {
+  if constexpr (CLS16) linear_to_lds_xrow<1, MODE>(X, ldx, L, Y, ldy);
+  else linear_to_lds<MB, MODE>(X, ldx, L, Y, ldy);
+}
+
+template <int DH, bool CLS16>
 __global__ __launch_bounds__(MMT_NT) void mmt_vit_kernel(mmt_vit V, VitLaunch P, const float *__restrict__ maps,
                                                          float *__restrict__ out) {
   extern __shared__ __align__(16) float smem[];
   const int dim = V.dim, ldx = P.ldx, lds = P.lds_scr, ntok = P.ntok;
-  float *xs = smem;              // [32][ldx] residual stream
-  float *ln = xs + 32 * ldx;     // [32][ldx] LayerNorm output (pre-norm blocks keep x untouched)
-  float *scr = ln + 32 * ldx;    // [32][lds] patch panel / q,k,v of one head group / FF hidden
+  constexpr int NR = CLS16 ? 17 : 32;   // rows of every LDS tile
+  float *xs = smem;              // [NR][ldx] residual stream
+  float *ln = xs + NR * ldx;     // [NR][ldx] LayerNorm output (pre-norm blocks keep x untouched)
+  float *scr = ln + NR * ldx;    // [NR][lds] patch panel / q,k,v of one head group / FF hidden
   const int tid = threadIdx.x, nt = blockDim.x;
   const int b = blockIdx.x;
   const int S = V.image, ps = V.patch, C = V.channels;
   const float *img = maps + (size_t)b * C * S * S;
 
-  for (int i = tid; i < 32 * (2 * ldx + lds); i += nt) smem[i] = 0.f;
+  for (int i = tid; i < NR * (2 * ldx + lds); i += nt) smem[i] = 0.f;
   __syncthreads();
 
   // ---- patch embedding, K streamed in panels; token row = 1 + patch index, row 0 (cls) stays zero here
@@ -54,25 +65,26 @@ __global__ __launch_bounds__(MMT_NT) void mmt_vit_kernel(mmt_vit V, VitLaunch P,
         v = img[((size_t)c * S + hi * ps + p1) * S + wi * ps + p2];
         if (V.input_affine) v = v * 2.0f - 1.0f;
       }
-      scr[(1 + p) * lds + kk] = v;
+      scr[(CLS16 ? p : 1 + p) * lds + kk] = v;
     }
     __syncthreads();
     mmt_linear L = V.patch_fc;
     L.w = V.patch_fc.w + pn * panel_stride;
     L.k = kw;
     if (pn == 0) {
-      linear_to_lds<2, EPI_STORE>(scr, lds, L, xs, ldx);
+      linear_to_lds<CLS16 ? 1 : 2, EPI_STORE>(scr, lds, L, xs, ldx);
     } else {
       L.b = nullptr;
-      linear_to_lds<2, EPI_ADD>(scr, lds, L, xs, ldx);
+      linear_to_lds<CLS16 ? 1 : 2, EPI_ADD>(scr, lds, L, xs, ldx);
     }
     __syncthreads();
   }
   // cls token and learned positions ('x += pos_embedding[:, :n+1]')
   for (int i = tid; i < ntok * dim; i += nt) {
-    const int r = i / dim, c = i - r * dim;
-    const float base = r == 0 ? V.cls_token[c] : xs[r * ldx + c];
-    xs[r * ldx + c] = base + V.pos_embedding[(size_t)r * dim + c];
+    const int t = i / dim, c = i - t * dim;                 // token t: 0 = cls
+    const int r = CLS16 ? (t == 0 ? 16 : t - 1) : t;
+    const float base = t == 0 ? V.cls_token[c] : xs[r * ldx + c];
+    xs[r * ldx + c] = base + V.pos_embedding[(size_t)t * dim + c];
   }
   __syncthreads();
 
@@ -86,12 +98,19 @@ __global__ __launch_bounds__(MMT_NT) void mmt_vit_kernel(mmt_vit V, VitLaunch P,
     layer_norm_rows_to(xs, ldx, ln, ldx, ntok, dim, W.ln1);
     __syncthreads();
     for (int g = 0; g < ngroups; ++g) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {        // q, k, v columns of this head group
+      if ((gw & 15) == 0) {                // q | k | v of this head group: three back-to-back blocks of whole slabs = one linear
         mmt_linear L = W.qkv;
-        L.w = W.qkv.w + (size_t)(g * 3 + t) * qkv_stride;
-        L.n = gw;
-        linear_to_lds<2, EPI_STORE>(ln, ldx, L, scr + t * gw, lds);
+        L.w = W.qkv.w + (size_t)(g * 3) * qkv_stride;
+        L.n = 3 * gw;
+        vit_linear<2, EPI_STORE, CLS16>(ln, ldx, L, scr, lds);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          mmt_linear L = W.qkv;
+          L.w = W.qkv.w + (size_t)(g * 3 + t) * qkv_stride;
+          L.n = gw;
+          vit_linear<2, EPI_STORE, CLS16>(ln, ldx, L, scr + t * gw, lds);
+        }
       }
       __syncthreads();
       for (int q16 = tid >> 4; q16 < ntok * hg; q16 += nt >> 4) {
@@ -105,20 +124,22 @@ __global__ __launch_bounds__(MMT_NT) void mmt_vit_kernel(mmt_vit V, VitLaunch P,
       L.w = W.out.w + (size_t)g * out_stride;
       L.k = gw;
       if (g != 0) L.b = nullptr;
-      linear_to_lds<2, EPI_ADD>(scr, lds, L, xs, ldx);
+      vit_linear<2, EPI_ADD, CLS16>(scr, lds, L, xs, ldx);
       __syncthreads();
     }
     layer_norm_rows_to(xs, ldx, ln, ldx, ntok, dim, W.ln2);
     __syncthreads();
-    linear_to_lds<2, EPI_GELU>(ln, ldx, W.ff1, scr, lds);
+    vit_linear<2, EPI_GELU, CLS16>(ln, ldx, W.ff1, scr, lds);
     __syncthreads();
-    linear_to_lds<2, EPI_ADD>(scr, lds, W.ff2, xs, ldx);
+    vit_linear<2, EPI_ADD, CLS16>(scr, lds, W.ff2, xs, ldx);
     __syncthreads();
   }
-  // cls pooling: LN + Linear on row 0 only
-  layer_norm_rows_to(xs, ldx, ln, ldx, 1, dim, V.head_ln);
+  // cls pooling: LN + Linear on the cls row only (the 15 rows after it -- zeros, or with CLS16 whatever follows in LDS -- are
+  // other rows of the MFMA tile: they never mix into row 0 and their outputs are not read)
+  constexpr int CR = CLS16 ? 16 : 0;
+  layer_norm_rows_to(xs + CR * ldx, ldx, ln + CR * ldx, ldx, 1, dim, V.head_ln);
   __syncthreads();
-  linear_to_lds<1, EPI_STORE>(ln, ldx, V.head_fc, scr, lds);
+  linear_to_lds<1, EPI_STORE>(ln + CR * ldx, ldx, V.head_fc, scr, lds);
   __syncthreads();
   for (int c = tid; c < V.n_out; c += nt) out[(size_t)b * V.n_out + c] = scr[c];
 }
@@ -145,13 +166,20 @@ extern "C" int mmt_vit_forward(const mmt_vit *vit, const float *maps, int B, flo
   P.ldx = V.dim + MMT_PAD;
   const int gw = V.heads_per_group * V.dim_head;
   P.lds_scr = std::max(std::max(3 * gw, V.mlp_dim), std::max(V.panel_k, (V.n_out + 15) & ~15)) + MMT_PAD;
-  const size_t lds = (size_t)32 * (2 * P.ldx + P.lds_scr) * sizeof(float);
+  const bool cls16 = ntok == 17;
+  // (CLS16: 17 rows; the cls pooling's MFMA tile starts at row 16 and runs 15 rows into what follows: keep that inside the allocation)
+  const size_t lds = cls16 ? std::max((size_t)17 * (2 * P.ldx + P.lds_scr), (size_t)(17 + 32) * P.ldx + 16 * P.lds_scr) * sizeof(float)
+                           : (size_t)32 * (2 * P.ldx + P.lds_scr) * sizeof(float);
   if (lds > 160 * 1024) return mmt_set_error(MMT_EINVAL, "mmt_vit_forward: tile needs %zu B of LDS (> 160 KiB)", lds);
 #define VIT_LAUNCH(DHV)                                                                                          \
   do {                                                                                                           \
-    (void)hipFuncSetAttribute((const void *)mmt_vit_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                              (int)lds);                                                                         \
-    hipLaunchKernelGGL((mmt_vit_kernel<DHV>), dim3(B), dim3(MMT_NT), lds, (hipStream_t)stream, V, P, maps, out);  \
+    if (cls16) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void *)mmt_vit_kernel<DHV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((mmt_vit_kernel<DHV, true>), dim3(B), dim3(MMT_NT), lds, (hipStream_t)stream, V, P, maps, out); \
+    } else {                                                                                                     \
+      (void)hipFuncSetAttribute((const void *)mmt_vit_kernel<DHV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((mmt_vit_kernel<DHV, false>), dim3(B), dim3(MMT_NT), lds, (hipStream_t)stream, V, P, maps, out); \
+    }                                                                                                            \
   } while (0)
   if (V.dim_head == 16) VIT_LAUNCH(16); else if (V.dim_head == 32) VIT_LAUNCH(32); else VIT_LAUNCH(64);
 #undef VIT_LAUNCH

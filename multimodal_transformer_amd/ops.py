@@ -387,7 +387,17 @@ class PackedVit:
         V = _lib.Vit()
         dim, heads, dh = cfg["dim"], cfg["heads"], cfg["dim_head"]
         inner = heads * dh
-        hg = self.HEADS_PER_GROUP if heads % self.HEADS_PER_GROUP == 0 else 1
+        # as many heads per q|k|v group as the LDS tile holds (fewer, wider linears and barriers per block): rows x (residual + LN
+        # + scratch of 3*gw columns) within 160 KiB; 17 rows when the kernel's 16-patch form applies, else 32
+        ntok = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+        rows, pad = (17 if ntok == 17 else 32), 8
+        hg = 1
+        for cand in range(heads, 0, -1):
+            scr = max(3 * cand * dh, cfg["mlp_dim"], self.PANEL_K, (cfg["num_classes"] + 15) & ~15) + pad
+            need = max(rows * (2 * (dim + pad) + scr), ((17 + 32) * (dim + pad) + 16 * scr) if rows == 17 else 0) * 4
+            if heads % cand == 0 and need <= 160 * 1024:
+                hg = cand
+                break
         gw = hg * dh
         V.image, V.patch, V.channels = cfg["image_size"], cfg["patch_size"], cfg["channels"]
         V.dim, V.depth, V.heads, V.dim_head, V.mlp_dim = dim, cfg["depth"], heads, dh, cfg["mlp_dim"]

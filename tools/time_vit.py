@@ -11,8 +11,11 @@ for B in (128, 1024):
     b = make_batch(B, 8, 12, seed=1, with_map=True)
     maps = torch.from_numpy(b["map"]).to(dev)
     vit = reg.model_dict["VEHICLE/map_encoder"]
+    class _NoDrop:
+        view = {}
     class E:
         device = dev
+        drop = _NoDrop()
         def _buf(self, *shape, dtype=torch.float32): return torch.zeros(*shape, dtype=dtype, device=dev)
     tape = training._VitTape(E(), vit, B, 2.0, -1.0)
     def avg(fn, n=30):
