@@ -379,7 +379,7 @@ class PackedVit:
     """vit_pytorch 0.33.2 ``ViT`` descriptor (state_dict names of that package; parity unpinned)."""
 
     HEADS_PER_GROUP = 2
-    PANEL_K = 256
+    PANEL_K = 1024
 
     def __init__(self, sd: dict, cfg: dict):
         dev = sd["cls_token"].device
