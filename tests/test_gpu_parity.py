@@ -367,6 +367,7 @@ def test_trajectron_batch_entry_points_match_reference_golden(mode):
     reg = ModelRegistrar("/tmp", dev)
     tr = Trajectron(reg, hp, None, dev)
     tr.set_environment(types.SimpleNamespace(NodeType=["VEHICLE"], get_edge_types=lambda: [], robot_type=None))
+    helpers.no_dropout(tr.node_models_dict["VEHICLE"])          # the goldens are dropout-free
     set_weights(reg.model_dict, True, z)
     b = batch_for(mode, True)
     t = {k: torch.from_numpy(v) for k, v in b.items()}          # host tensors, like a DataLoader batch
