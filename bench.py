@@ -268,7 +268,9 @@ def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, grou
                            f"rank 0 at start" if world > 1 else "single GPU",
             "dropout": ({"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
                          "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
-                         "decode": "step by step on the stash kernels (tokens depend on the masks)"} if dropout else 0.0),
+                         "decode": ("mmt_decoder_forward_dropout: launch-per-phase 4-agent-cluster kernels reading the step's keep masks"
+                                    if tr.engine._ar_decode_takes_masks() else
+                                    "step by step on the stash kernels (tokens depend on the masks)")} if dropout else 0.0),
             "last_loss_rank0": float(loss),
             "algorithmic_tflops": 3 * (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * world * steps / elapsed / 1e12}
 

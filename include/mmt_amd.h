@@ -319,6 +319,27 @@ int mmt_pack_conv(const float *w, int Co, int Ci, int ks, float *dst, void *stre
 size_t mmt_cnn_workspace_floats(const mmt_cnn *cnn, int B);
 int mmt_cnn_forward(const mmt_cnn *cnn, const float *maps, int B, float *out, float *workspace, void *stream);
 
+/* ---- the autoregressive decode of a TRAINING step (mgcvae.py:375-449 with the modules in training mode): the reference's
+ * nn.Dropout / attention-probability dropouts of Trajectory_Decoder (Transformer_model.py:77-79,126-129) applied from keep
+ * bytes the caller drew (mmt_dropout_mask), so that the positions fed back are the ones the training step's stash pass and
+ * backward see.  Sites are laid out like the training step's stash: `pe`, `drop1/2/3[l]` (ph, B, d) step-major, `ff[l]`
+ * (ph, B, d_ff), `attn1[l]` (B, H, ph, ph), `attn2[l]` (B, H, ph, T); a NULL site is not dropped; *_scale = 1/(1-p).
+ * Runs on the launch-per-phase 4-agent-cluster kernels only (mmt_decoder_dropout_supported: head dimension 32, lin4 weight
+ * copies present, batch small enough for 4-agent clusters -- B <= 128 on 256 CUs); otherwise MMT_EINVAL, and the caller decodes
+ * step by step on the training kernels (training.py).  No teacher-forced form: with given tokens the stash pass is the decode. */
+typedef struct {
+  const uint8_t *pe;
+  const uint8_t *attn1[MMT_MAX_LAYERS], *drop1[MMT_MAX_LAYERS], *attn2[MMT_MAX_LAYERS], *drop2[MMT_MAX_LAYERS],
+      *ff[MMT_MAX_LAYERS], *drop3[MMT_MAX_LAYERS];
+  float pe_scale;
+  float attn1_scale[MMT_MAX_LAYERS], drop1_scale[MMT_MAX_LAYERS], attn2_scale[MMT_MAX_LAYERS], drop2_scale[MMT_MAX_LAYERS],
+      ff_scale[MMT_MAX_LAYERS], drop3_scale[MMT_MAX_LAYERS];
+} mmt_decoder_dropout;
+int mmt_decoder_dropout_supported(const mmt_decoder *dec, int B, int T, int ph);
+int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
+                                const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim, int B, int T,
+                                int ph, float *pred_st, float *workspace, const mmt_decoder_dropout *drop, void *stream);
+
 /* ---- ViT.forward (vit_pytorch 0.33.2 architecture; parity unpinned): maps (B,C,S,S) -> (B,n_out) ------------ */
 int mmt_vit_forward(const mmt_vit *vit, const float *maps, int B, float *out, void *stream);
 

@@ -57,6 +57,12 @@ class Decoder(C.Structure):
                 ("map_fusion", Mlp), ("has_mem_fusion", C.c_int32), ("mem_fusion", Mlp)]
 
 
+class DecoderDropout(C.Structure):
+    _fields_ = [("pe", fptr)] + [(n, fptr * MMT_MAX_LAYERS) for n in ("attn1", "drop1", "attn2", "drop2", "ff", "drop3")] + \
+               [("pe_scale", C.c_float)] + [(n + "_scale", C.c_float * MMT_MAX_LAYERS)
+                                            for n in ("attn1", "drop1", "attn2", "drop2", "ff", "drop3")]
+
+
 class Cnn(C.Structure):
     _fields_ = [("nconv", C.c_int32), ("in_ch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
                 ("out_ch", C.c_int32 * MMT_MAX_CONV), ("ksize", C.c_int32 * MMT_MAX_CONV),
@@ -135,6 +141,9 @@ SIGNATURES = {
                                       C.c_int, C.c_int, C.c_int, fptr, fptr, fptr, C.c_void_p]),
     "mmt_decoder_forward_static": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, fptr,
                                              C.c_int, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
+    "mmt_decoder_dropout_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
+    "mmt_decoder_forward_dropout": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, fptr, fptr, C.POINTER(DecoderDropout), C.c_void_p]),
     "mmt_decoder_status": (C.c_int, [C.c_void_p]),
     "mmt_decoder_last_path": (C.c_int, []),
     "mmt_debug_decoder_stall": (C.c_int, [C.c_int]),

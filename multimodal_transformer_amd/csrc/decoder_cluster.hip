@@ -93,6 +93,10 @@ struct ClArgs {
   const float *start_pos, *tgt, *map_feat;
   float *pred_st, *h_out;
   const unsigned *tmo;              // time-out word of the fused kernel (NULL: launch-per-phase path); read by the final head launch
+  // training-mode dropout (mmt_decoder_forward_dropout; DROP instantiations of the launch-per-phase kernels only): keep bytes of
+  // THIS launch, already offset to its decoder step (NULL: that site is not dropped), and the 1/(1-p) of each
+  const uint8_t *dk_red, *dk_pe, *dk_ff, *dk_att;      // sub-layer output summed by this launch's reduce | embedding + pe | FFN hidden | attention probabilities
+  float ds_red, ds_pe, ds_ff, ds_att;
 };
 static_assert(offsetof(ClArgs, input_fc) == 160, "hot block of ClArgs");
 
@@ -227,6 +231,12 @@ __device__ __forceinline__ void ns_mfma_store(const NsW<NS_KMAX> &r, const float
 
 // ------------------------------------------------------------------------------- x = LN(res + bias + sum_g part[g])
 // 32 lanes per row, two float4 column groups per lane (d <= 256).  Summation order is fixed.
+// four keep bytes (one aligned 32-bit load) -> the factors 0 | scale of four consecutive columns
+__device__ __forceinline__ f32x4 keep4(const uint8_t *p, size_t off, float scale) {
+  const unsigned kb = *reinterpret_cast<const unsigned *>(p + off);
+  return (f32x4){(kb & 0xffu) ? scale : 0.f, (kb & 0xff00u) ? scale : 0.f, (kb & 0xff0000u) ? scale : 0.f, (kb & 0xff000000u) ? scale : 0.f};
+}
+
 struct RedRegs {
   f32x4 res[2], bias[2], gam[2], bet[2], p[2][8];
 };
@@ -248,6 +258,8 @@ __device__ __forceinline__ void reduce_issue(RedRegs &R, const ClArgs &a, int cl
     R.bet[j] = bl4(rbt, co);
   }
 }
+// DROP: res + keep * (bias + sum_g part[g]): the summed sub-layer output went through dropout before the residual add
+template <bool DROP = false>
 __device__ __forceinline__ void reduce_finish(const RedRegs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res) {
   const int tid = thread_idx(), row = tid >> 5, l32 = tid & 31, nq = a.d >> 2;
   const bool live = row < a.RC;
@@ -256,6 +268,18 @@ __device__ __forceinline__ void reduce_finish(const RedRegs &R, const ClArgs &a,
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     f32x4 acc = R.res[j] + R.bias[j];
+    if constexpr (DROP) {
+      const int ag = cluster * a.RC + row, q = l32 + 32 * j;
+      if (a.dk_red && live && ag < a.B && q < nq) {
+        f32x4 t = R.bias[j];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += R.p[j][g];
+        acc = R.res[j] + keep4(a.dk_red, (size_t)ag * a.d + 4 * q, a.ds_red) * t;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc += R.p[j][g];
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < 8; ++g) acc += R.p[j][g];      // unused slots hold zeros
     v[j] = acc;
@@ -323,7 +347,8 @@ __device__ __forceinline__ unsigned tag_of_phase(unsigned p) { return (p >> 3) &
 __device__ __forceinline__ unsigned phase_tag(const ClArgs &a) { return tag_of_phase((unsigned)a.prof_idx); }   // prof_idx = phase p
 
 // x = tok W_in^T + b + pe[s]  (Transformer_model.py:100-102); tok is a 16x16 LDS tile (n_in <= 16)
-template <bool SC1 = false>
+// DROP: x = dropout(...) with this step's keep bytes (PositionalEncoding.dropout, Transformer_model.py:126-129)
+template <bool SC1 = false, bool DROP = false>
 __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const float *tok, float *xs, int ldx, bool write_res) {
   const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
   const f32x4 *W4 = reinterpret_cast<const f32x4 *>(a.input_fc.w) + lane;
@@ -338,6 +363,10 @@ __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       float y = acc[rr] + add;
+      if constexpr (DROP) {
+        const int ag = cluster * a.RC + row0 + rr;
+        if (a.dk_pe && row0 + rr < a.RC && ag < a.B) y = a.dk_pe[(size_t)ag * a.d + col] ? y * a.ds_pe : 0.f;
+      }
       if (a.tagged) y = tag1(y, (unsigned)a.s & TAG_MASK);            // the embedded token of step s
       xs[(row0 + rr) * ldx + col] = y;
       if (write_res && row0 + rr < a.RC) {
@@ -509,7 +538,7 @@ __device__ __forceinline__ void cluster_of_block(int G, int &cluster, int &g) {
   }
 }
 
-template <int DH, int CPW, int PHASE, int XMODE>
+template <int DH, int CPW, int PHASE, int XMODE, bool DROP = false>
 __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   extern __shared__ __align__(16) float smem[];
   const int d = a.d, ldx = d + MMT_PAD, D16 = d >> 4, K16 = D16;
@@ -557,7 +586,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
   __syncthreads();
 
   // ---- 2. input of this sub-layer
-  if (red_wave) reduce_finish(R, a, cluster, xs, ldx, g == 0 && !HEAD);
+  if (red_wave) reduce_finish<DROP>(R, a, cluster, xs, ldx, g == 0 && !HEAD);
   else if (REDUCES) {                               // rows beyond the cluster: zeros (finite MFMA operands)
     const int row = tid >> 5, l32 = tid & 31;
     for (int q = l32; q < (d >> 2); q += 32) *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -745,14 +774,27 @@ __device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int 
   R.gam = bl4(mk_rsrc(a.red_ln.g), co);
   R.bet = bl4(mk_rsrc(a.red_ln.b), co);
 }
-template <int AUX = AUX_PLAIN>
+template <int AUX = AUX_PLAIN, bool DROP = false>
 __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res,
                                                bool tag_rows = true) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
   f32x4 acc = R.res + R.bias;
+  bool dropped = false;
+  if constexpr (DROP) {            // res + keep * (bias + sum of the parts)
+    const int ag = cluster * 4 + row;
+    if (a.dk_red && live && ag < a.B) {
+      f32x4 t = R.bias;
 #pragma unroll
-  for (int g = 0; g < 8; ++g) acc += R.p[g];          // unused slots hold zeros
+      for (int g = 0; g < 8; ++g) t += R.p[g];
+      acc = R.res + keep4(a.dk_red, (size_t)ag * a.d + 4 * q, a.ds_red) * t;
+      dropped = true;
+    }
+  }
+  if (!dropped) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc += R.p[g];          // unused slots hold zeros
+  }
   const float mu = wave64_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) / (float)a.d;     // lanes beyond d/4 hold zeros
   float var = 0.f;
   if (live) {
@@ -869,8 +911,10 @@ __device__ __forceinline__ void kv_issue4(MainRegs4<DH, PHASE> &M, const ClArgs 
 }
 
 // t1[0..3][columns of head g] = x W1slice^T + b (+ReLU in phase C)
-template <int DH, int PHASE>
-__device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *xs, int ldx, float *t1, int ld1) {
+// DROP (phase C): hidden = dropout(relu(.)) with the keep bytes of (agent a0 + r, hidden column g*FS + col)
+template <int DH, int PHASE, bool DROP = false>
+__device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClArgs &a, const float *xs, int ldx, float *t1, int ld1,
+                                        int a0 = 0, int na = 0, int g = 0) {
   typedef Geom4<PHASE> G4;
   const int KQ = a.d >> 2, FS = a.FS16 * 16, w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
   const Lin4 L1 = lin4((PHASE == PH_C ? FS : DH) / 4, KQ);
@@ -902,7 +946,13 @@ __device__ __forceinline__ void gemm1_4(const MainRegs4<DH, PHASE> &M, const ClA
   } else if (b < (PHASE == PH_C ? L1.cgw : 1)) {
     const int col = (w * L1.cgw + b) * 4 + j;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t1[r * ld1 + col] = PHASE == PH_C ? fmaxf(acc[0][r] + M.b1, 0.f) : acc[0][r] + M.b1;
+    for (int r = 0; r < 4; ++r) {
+      float v = PHASE == PH_C ? fmaxf(acc[0][r] + M.b1, 0.f) : acc[0][r] + M.b1;
+      if constexpr (DROP && PHASE == PH_C) {
+        if (a.dk_ff && r < na) v = a.dk_ff[(size_t)(a0 + r) * (FS * a.H) + g * FS + col] ? v * a.ds_ff : 0.f;
+      }
+      t1[r * ld1 + col] = v;
+    }
   }
 }
 
@@ -974,7 +1024,7 @@ __device__ __forceinline__ void cluster_arrive(FusedSync &fs) {
 // One phase (A, B or C) of one layer-step for a cluster of 4 agents; the head-only launch stays on mmt_dec_phase_kernel.
 // FUSED: called from the fused kernel's loop - waits for the cluster's previous phase instead of a kernel boundary, stores what
 // other workgroups read write-through and loads it past the L1.
-template <int DH, int CPW, int PHASE, int XMODE, bool FUSED>
+template <int DH, int CPW, int PHASE, int XMODE, bool FUSED, bool DROP = false>
 __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g, float *smem, FusedSync &fs) {
   static_assert(DH == 32 && PHASE != PH_H, "4x4x1 path: 8 column groups per head, one per wave");
   constexpr int AUX = FUSED ? AUX_SC1 : AUX_PLAIN;
@@ -1026,7 +1076,7 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
   }
 
   // ---- 2. input of this sub-layer
-  if (red_wave) reduce4_finish<AUX>(R, a, cluster, xs, ldx, g == 0 && !HEAD, !HEAD);
+  if (red_wave) reduce4_finish<AUX, DROP>(R, a, cluster, xs, ldx, g == 0 && !HEAD, !HEAD);
   if constexpr (HEAD) {
     head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur, FUSED ? pos : nullptr);
     main_issue4<DH, PHASE, AUX>(M, a, a0, na, g);
@@ -1040,13 +1090,13 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
                                    : a.start_pos[(size_t)(a0 + r) * a.n_in + c];
       }
     __syncthreads();
-    embed_token<FUSED>(a, cluster, tok, xs, ldx, g == 0);
+    embed_token<FUSED, DROP>(a, cluster, tok, xs, ldx, g == 0);
   }
   __syncthreads();
   CSTAMP(2);
 
   // ---- 3. first linear; K/V cache rows from registers to their staging tiles
-  gemm1_4<DH, PHASE>(M, a, xs, ldx, t1, LD1);
+  gemm1_4<DH, PHASE, DROP>(M, a, xs, ldx, t1, LD1, a0, na, g);
   if constexpr (PHASE != PH_C) {
     const int nglob = PHASE == PH_A ? a.s : a.T;
 #pragma unroll
@@ -1088,6 +1138,10 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
       float p = mx > -INFINITY ? expf(sc - mx) : 0.f;    // a fully masked row yields zeros (reference: undefined / NaN)
       const float sum = row16_sum(p);
       p *= sum > 0.f ? 1.0f / sum : 0.f;
+      if constexpr (DROP) {          // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p), training mode)
+        const int Lk = PHASE == PH_A ? a.ph : a.T;
+        if (a.dk_att && !masked) p = a.dk_att[((size_t)(a0 + ar) * a.H + g) * a.ph * Lk + l16] ? p * a.ds_att : 0.f;
+      }
       ps[tid] = p;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ps is written and read by this wave only
       __builtin_amdgcn_wave_barrier();
@@ -1133,13 +1187,13 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
   return true;
 }
 
-template <int DH, int CPW, int PHASE, int XMODE>
+template <int DH, int CPW, int PHASE, int XMODE, bool DROP = false>
 __global__ __launch_bounds__(CNT) void mmt_dec_phase4_kernel(ClArgs a) {
   extern __shared__ __align__(16) float smem[];
   int cluster, g;
   cluster_of_block(a.H, cluster, g);
   FusedSync fs = {};
-  phase4_body<DH, CPW, PHASE, XMODE, false>(a, cluster, g, smem, fs);
+  phase4_body<DH, CPW, PHASE, XMODE, false, DROP>(a, cluster, g, smem, fs);
 }
 
 // ------------------------------------------------------------------------------- fused kernel: every phase of a decode in ONE launch
@@ -2036,7 +2090,7 @@ static PipeGeom pipe_geom(int L, int H, int NC, int ncu) {
 
 template <int DH, int CPW, bool M4>
 static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], float *memkv, float *selfkv,
-                         unsigned *sync, int one_launch, const PipeGeom &pg, hipStream_t st) {
+                         unsigned *sync, int one_launch, const PipeGeom &pg, hipStream_t st, const mmt_decoder_dropout *drop = nullptr) {
   const bool fused = one_launch != ONE_LAUNCH_NONE;
   const int d = dec->d_model, H = dec->nhead, NC = (B + a.RC - 1) / a.RC, L = dec->nlayers;
   constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
@@ -2049,8 +2103,14 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 #define SET_LDS(PHASE, XM, BYTES)                                                                                                     \
   do {                                                                                                                                \
     (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PHASE, XM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)); \
-    if constexpr (M4 && PHASE != PH_H)                                                                                                \
+    if constexpr (M4 && PHASE != PH_H) {                                                                                              \
       (void)hipFuncSetAttribute((const void *)mmt_dec_phase4_kernel<DH, CPW, PHASE == PH_H ? PH_C : PHASE, XM>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));                                            \
+      (void)hipFuncSetAttribute((const void *)mmt_dec_phase4_kernel<DH, CPW, PHASE == PH_H ? PH_C : PHASE, XM, true>,                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));                                            \
+    }                                                                                                                                 \
+    if constexpr (M4 && PHASE == PH_H)                                                                                                \
+      (void)hipFuncSetAttribute((const void *)mmt_dec_phase_kernel<DH, CPW, PH_H, XM_REDUCE, true>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES));                                            \
   } while (0)
     SET_LDS(PH_A, XM_EMBED, lds_a);
@@ -2070,9 +2130,33 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   }
 #define LAUNCH_PHASE(PHASE, XM, BYTES)                                                                     \
   do {                                                                                                     \
-    if constexpr (M4) hipLaunchKernelGGL((mmt_dec_phase4_kernel<DH, CPW, PHASE, XM>), grid, blk, BYTES, st, a); \
-    else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PHASE, XM>), grid, blk, BYTES, st, a);          \
+    if constexpr (M4) {                                                                                    \
+      if (drop) hipLaunchKernelGGL((mmt_dec_phase4_kernel<DH, CPW, PHASE, XM, true>), grid, blk, BYTES, st, a); \
+      else hipLaunchKernelGGL((mmt_dec_phase4_kernel<DH, CPW, PHASE, XM>), grid, blk, BYTES, st, a);       \
+    } else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PHASE, XM>), grid, blk, BYTES, st, a);        \
   } while (0)
+  // training-mode dropout: the keep bytes of one launch (sites laid out like the training step's stash: (ph, B, .) step-major,
+  // attention sites (B, H, ph, Lk)); NULL sites stay NULL
+  const size_t Bd = (size_t)B * d, Bf = (size_t)B * dec->d_ff;
+  auto site = [](const uint8_t *base, size_t off) -> const uint8_t * { return base ? base + off : nullptr; };
+  auto drop_of = [&](ClArgs &x, int phase, int l, int s) {
+    if (!drop) return;
+    x.dk_red = x.dk_pe = x.dk_ff = x.dk_att = nullptr;
+    if (phase == PH_A) {
+      if (l > 0) x.dk_red = site(drop->drop3[l - 1], (size_t)s * Bd), x.ds_red = drop->drop3_scale[l - 1];
+      else if (s > 0) x.dk_red = site(drop->drop3[L - 1], (size_t)(s - 1) * Bd), x.ds_red = drop->drop3_scale[L - 1];
+      if (l == 0) x.dk_pe = site(drop->pe, (size_t)s * Bd), x.ds_pe = drop->pe_scale;
+      x.dk_att = site(drop->attn1[l], (size_t)s * ph), x.ds_att = drop->attn1_scale[l];
+    } else if (phase == PH_B) {
+      x.dk_red = site(drop->drop1[l], (size_t)s * Bd), x.ds_red = drop->drop1_scale[l];
+      x.dk_att = site(drop->attn2[l], (size_t)s * x.T), x.ds_att = drop->attn2_scale[l];
+    } else if (phase == PH_C) {
+      x.dk_red = site(drop->drop2[l], (size_t)s * Bd), x.ds_red = drop->drop2_scale[l];
+      x.dk_ff = site(drop->ff[l], (size_t)s * Bf), x.ds_ff = drop->ff_scale[l];
+    } else {
+      x.dk_red = site(drop->drop3[L - 1], (size_t)(ph - 1) * Bd), x.ds_red = drop->drop3_scale[L - 1];
+    }
+  };
   int p = 0;   // phase counter: phase p writes part[p&1] / xres[p&1] and reads the other pair
   auto bufs = [&](ClArgs &x) {
     x.part_out = part[p & 1];
@@ -2146,6 +2230,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       a.red_bias = prev.ff2.b;
       a.red_ln = prev.ln3;
       bufs(a);
+      drop_of(a, PH_A, l, s);
       if (l > 0) LAUNCH_PHASE(PH_A, XM_REDUCE, lds_a);
       else if (s == 0) LAUNCH_PHASE(PH_A, XM_EMBED, lds_a);
       else LAUNCH_PHASE(PH_A, XM_HEAD_EMBED, lds_a);
@@ -2156,6 +2241,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       a.w2 = M4 ? W.cout4 : W.cout.w;
       a.kv = memkv;
       bufs(a);
+      drop_of(a, PH_B, l, s);
       LAUNCH_PHASE(PH_B, XM_REDUCE, lds_a);
       a.red_bias = W.cout.b;
       a.red_ln = W.ln2;
@@ -2163,6 +2249,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
       a.b1 = W.ff1.b;
       a.w2 = M4 ? W.ff24 : W.ff2.w;
       bufs(a);
+      drop_of(a, PH_C, l, s);
       LAUNCH_PHASE(PH_C, XM_REDUCE, lds_c);
     }
   }
@@ -2170,6 +2257,11 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
   a.red_bias = last.ff2.b;
   a.red_ln = last.ln3;
   bufs(a);
+  drop_of(a, PH_H, L - 1, ph);
+  if constexpr (M4) {
+    if (drop) hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_H, XM_REDUCE, true>), dim3(NC), blk, lds_c, st, a);
+    else hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_H, XM_REDUCE>), dim3(NC), blk, lds_c, st, a);
+  } else
   hipLaunchKernelGGL((mmt_dec_phase_kernel<DH, CPW, PH_H, XM_REDUCE>), dim3(NC), blk, lds_c, st, a);
 #undef LAUNCH_PHASE
   CL_CHECK("mmt_decoder_forward (cluster phases)");
@@ -2228,13 +2320,23 @@ extern "C" int mmt_debug_decoder_stall(int on) {
 }
 
 // Same contract as mmt_decoder_forward (arguments already validated there).
+bool mmt_cluster_decoder_dropout_ok(const mmt_decoder *dec, int B) {
+  return cluster_rows(B, dec->nhead) == 4 && mfma4_fits(dec);
+}
+
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                int allow_fused, void *stream) {      // 0: launch per phase, 1: fused kernel, 2: pipeline, 3: best
+                                int allow_fused, void *stream, const mmt_decoder_dropout *drop) {      // 0: launch per phase, 1: fused kernel, 2: pipeline, 3: best
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d_model, H = dec->nhead, L = dec->nlayers;
   const int RC = cluster_rows(B, H), NC = (B + RC - 1) / RC;
+  if (drop) {
+    if (!mmt_cluster_decoder_dropout_ok(dec, B) || tgt)
+      return mmt_set_error(MMT_EINVAL, "mmt_decoder_forward_dropout: only the autoregressive decode on the 4-agent-cluster kernels "
+                                       "(head dimension 32, lin4 weight copies, batch small enough for 4-agent clusters) takes keep masks");
+    allow_fused = 0;                // the launch-per-phase kernels are the ones instantiated with the mask reads
+  }
   float *memkv = workspace;
   float *selfkv = memkv + (size_t)L * B * T * 2 * d;
   float *extra = selfkv + (size_t)L * B * ph * 2 * d;
@@ -2347,8 +2449,8 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   const bool cpw2 = d > 128;
   if (m4) {
     // (CPW still sizes the K-split of the head's small linears, which stay on 16x16x4 tiles)
-    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st)
-                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st);
+    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st, drop)
+                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st, drop);
   }
   if (dh == 32)
     return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st)

@@ -506,10 +506,11 @@ static int encoder_forward_impl(const mmt_encoder *enc, const float *x_st, int B
 // decoder_cluster.hip
 bool mmt_cluster_decoder_supports(const mmt_decoder *dec, int map_dim, bool autoregressive, int T, int ph);
 size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T);
+bool mmt_cluster_decoder_dropout_ok(const mmt_decoder *dec, int B);
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                int allow_fused, void *stream);
+                                int allow_fused, void *stream, const mmt_decoder_dropout *drop);
 
 static thread_local int g_last_path = MMT_PATH_NONE;
 void mmt_note_decoder_path(int path) { g_last_path = path; }
@@ -528,10 +529,10 @@ extern "C" size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, in
   return (size_t)dec->nlayers * B * (size_t)(T + ph) * 2 * dec->d_model + mmt_cluster_decoder_extra_floats(dec, B, T);
 }
 
-extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
-                                   const float *start_pos, const float *map_feat, int map_dim, const float *mem_feat,
-                                   int mem_feat_dim, const float *tgt, int B, int T, int ph, float *pred_st,
-                                   float *h_out, float *workspace, void *stream) {
+static int decoder_forward_impl(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
+                                const float *start_pos, const float *map_feat, int map_dim, const float *mem_feat,
+                                int mem_feat_dim, const float *tgt, int B, int T, int ph, float *pred_st,
+                                float *h_out, float *workspace, void *stream, const mmt_decoder_dropout *drop) {
   if (!dec || !memory || !workspace) return fail(MMT_EINVAL, "mmt_decoder_forward: null pointer");
   const int g_decoder_impl = g_decoder_impl_atomic.load(std::memory_order_relaxed);
   if (B <= 0) return fail(MMT_EINVAL, "mmt_decoder_forward: empty batch (B=%d)", B);
@@ -575,11 +576,12 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     use_cluster = 2 * ((B + 15) / 16) * dec->nhead <= 5 * ncu;
   }
-  if (use_cluster)
+  if (drop && !cluster_ok) return fail(MMT_EINVAL, "mmt_decoder_forward_dropout: this geometry has no cluster decoder");
+  if (use_cluster || drop)
     return mmt_cluster_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T,
                                        ph, pred_st, h_out, workspace,
                                        g_decoder_impl == MMT_DECODER_CLUSTER_LAUNCHES ? 0 : g_decoder_impl == MMT_DECODER_CLUSTER_FUSED ? 1
-                                       : g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE ? 2 : 3, stream);
+                                       : g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE ? 2 : 3, stream, drop);
   mmt_note_decoder_path(MMT_PATH_PERSISTENT);
   // buf = [ region A | region B ], region B additionally split in two for the map-fusion ping-pong
   const int half = std::max((3 * d + 1) / 2, 2 * (small + MMT_PAD));
@@ -614,6 +616,29 @@ extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, 
   if (dh == 16) DEC_LAUNCH(16); else if (dh == 32) DEC_LAUNCH(32); else DEC_LAUNCH(64);
 #undef DEC_LAUNCH
   return check_launch("mmt_decoder_forward");
+}
+
+extern "C" int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
+                                   const float *start_pos, const float *map_feat, int map_dim, const float *mem_feat,
+                                   int mem_feat_dim, const float *tgt, int B, int T, int ph, float *pred_st,
+                                   float *h_out, float *workspace, void *stream) {
+  return decoder_forward_impl(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T, ph, pred_st,
+                              h_out, workspace, stream, nullptr);
+}
+
+// The autoregressive decode of a TRAINING step: the same kernels reading the step's dropout keep masks (include/mmt_amd.h).
+extern "C" int mmt_decoder_dropout_supported(const mmt_decoder *dec, int B, int T, int ph) {
+  if (!dec || B <= 0) return 0;
+  if (!mmt_cluster_decoder_supports(dec, dec->has_map_fusion ? 1 : 0, true, T, ph)) return 0;
+  return mmt_cluster_decoder_dropout_ok(dec, B) ? 1 : 0;
+}
+extern "C" int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
+                                           const float *start_pos, const float *map_feat, int map_dim, const float *mem_feat,
+                                           int mem_feat_dim, int B, int T, int ph, float *pred_st, float *workspace,
+                                           const mmt_decoder_dropout *drop, void *stream) {
+  if (!drop) return fail(MMT_EINVAL, "mmt_decoder_forward_dropout: null mask descriptor");
+  return decoder_forward_impl(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, nullptr, B, T, ph, pred_st,
+                              nullptr, workspace, stream, drop);
 }
 
 // ---- the same decode for callers that cannot allocate (include/mmt_amd.h: mmt_decoder_forward_static) ----------------------

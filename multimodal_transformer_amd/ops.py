@@ -570,10 +570,41 @@ def _encoder_workspace(nfloats, device):
     return buf
 
 
+def decoder_dropout_supported(dec: PackedDecoder, B, T, ph):
+    """Whether ``decoder_forward(..., dropout=...)`` can run this shape (the 4-agent-cluster kernels are the ones that read masks)."""
+    return bool(_lib.load().mmt_decoder_dropout_supported(C.byref(dec.desc), int(B), int(T), int(ph)))
+
+
+def _dropout_desc(dec, sites, B, T, ph):
+    """mmt_decoder_dropout from {site name: (uint8 keep tensor, scale) | None} with the training step's site names and shapes
+    ('dec.pe', 'dec{l}.attn1|drop1|attn2|drop2|ff|drop3')."""
+    D = _lib.DecoderDropout()
+    H, d, f = dec.desc.nhead, dec.desc.d_model, dec.desc.d_ff
+
+    def put(name, shape):
+        v = sites.get(name)
+        if v is None:
+            return 0, 0.0
+        keep, scale = v
+        if keep.dtype != torch.uint8 or not keep.is_cuda or not keep.is_contiguous() or keep.numel() != shape:
+            raise MmtError(f"dropout site {name}: expected a contiguous device uint8 tensor of {shape} elements")
+        return keep.data_ptr(), float(scale)
+
+    D.pe, D.pe_scale = put("dec.pe", ph * B * d)
+    for l in range(dec.desc.nlayers):
+        for kind, n in (("attn1", B * H * ph * ph), ("drop1", ph * B * d), ("attn2", B * H * ph * T), ("drop2", ph * B * d),
+                        ("ff", ph * B * f), ("drop3", ph * B * d)):
+            ptr, sc = put(f"dec{l}.{kind}", n)
+            getattr(D, kind)[l] = ptr
+            getattr(D, kind + "_scale")[l] = sc
+    return D
+
+
 def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12, map_feat=None, mem_feat=None,
-                    tgt=None, want_h=False, pred_out=None):
+                    tgt=None, want_h=False, pred_out=None, dropout=None):
     """Autoregressive (tgt=None) or teacher-forced decode.  Returns (pred_st (B,ph,n_in) | None, h (B,ph,n_out) | None).
-    ``pred_out``: caller-owned (B,ph,n_in) buffer for the autoregressive result (no allocation in this call)."""
+    ``pred_out``: caller-owned (B,ph,n_in) buffer for the autoregressive result (no allocation in this call).
+    ``dropout``: {site: (keep, scale) | None} -- the training step's decode with its keep masks (autoregressive only)."""
     _chk(memory, "memory", (None, None, dec.d_model))
     B, T, _ = memory.shape
     if pad_mask is not None:
@@ -603,6 +634,14 @@ def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12,
     h = torch.empty(B, ph, dec.n_out, dtype=torch.float32, device=dev) if (want_h or tgt is not None) else None
     lib = _lib.load()
     ws = _workspace(lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph), dev)
+    if dropout is not None:
+        if tgt is not None or want_h:
+            raise MmtError("decoder_forward: keep masks go with the autoregressive decode only")
+        D = _dropout_desc(dec, dropout, B, T, ph)
+        _lib.check(lib.mmt_decoder_forward_dropout(C.byref(dec.desc), _ptr(memory), _ptr(pad_mask), _ptr(start_pos), _ptr(map_feat),
+                                                   md, _ptr(mem_feat), mf, B, T, ph, _ptr(pred), _ptr(ws), C.byref(D), _stream()),
+                   "mmt_decoder_forward_dropout")
+        return pred, None
     _lib.check(lib.mmt_decoder_forward(C.byref(dec.desc), _ptr(memory), _ptr(pad_mask), _ptr(start_pos), _ptr(map_feat),
                                        md, _ptr(mem_feat), mf, _ptr(tgt), B, T, ph, _ptr(pred), _ptr(h), _ptr(ws),
                                        _stream()), "mmt_decoder_forward")

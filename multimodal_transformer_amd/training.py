@@ -718,9 +718,10 @@ class TrainEngine:
             R = ph * B
             self.head_tape.forward_out(self._head_z, S.delta.view(R, self.n_pos))
             K.cumsum_axis(S.delta.view(1, ph, B * self.n_pos), S.pos[1:].view(1, ph, B * self.n_pos), 1)
-        elif self.drop.active:
-            # With dropout the fed-back positions depend on the masks: the decode runs step by step on the stash kernels (the
-            # KV-cached recurrence, one query per agent against the keys of steps 0..s), which also IS the stash pass.
+        elif self.drop.active and not self._ar_decode_takes_masks():
+            # With dropout the fed-back positions depend on the masks.  Where the inference decoder kernels cannot read them (not
+            # the 4-agent-cluster geometry) the decode runs step by step on the stash kernels (the KV-cached recurrence, one
+            # query per agent against the keys of steps 0..s), which also IS the stash pass.
             for s_ in range(ph):
                 self._decoder_steps(s_, s_ + 1)
                 self.head_tape.forward_out(self._head_z, S.pos[s_ + 1], addend=S.pos[s_])
@@ -783,9 +784,28 @@ class TrainEngine:
             K.gemm(f2(S.x[self.Ld]), _t(dec.output_fc.weight), f2(S.ho), bias=dec.output_fc.bias)
             self._head_z = self.head_tape.forward_hidden(f2(S.ho), (r0, r1))
 
+    def _packed_decoder(self):
+        if self._pdec is None:      # packed copies alias the parameters: built once, refreshed in place every step
+            def dev_sd(m):
+                return {k: v.detach() for k, v in m.state_dict(keep_vars=True).items()}
+            self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head),
+                                           dev_sd(self.fuse) if self.map_mode else None,
+                                           dev_sd(self.memfuse) if self.lane_mode else None)
+            self._pdec_fresh = True
+        return self._pdec
+
+    def _ar_decode_takes_masks(self):
+        """Whether the inference decoder kernels can apply this step's keep masks (mmt_decoder_forward_dropout)."""
+        ok = self.__dict__.get("_ar_masks_ok")
+        if ok is None:
+            ok = self.__dict__["_ar_masks_ok"] = (torch.device(self.device).type == "cuda" and
+                                                  ops.decoder_dropout_supported(self._packed_decoder(), self.B, self.T, self.ph))
+        return ok
+
     def _ar_decode(self):
         """pos[1:] <- the 12-step autoregressive decode of the current parameters (mgcvae.py:375-449) on the fused
-        decoder kernels, from the encoder output and start token already in the stash."""
+        decoder kernels, from the encoder output and start token already in the stash; with dropout active, on the
+        launch-per-phase cluster kernels reading this step's keep masks."""
         S = self.s
         if self._pdec is None:      # packed copies alias the parameters: built once, refreshed in place every step
             def dev_sd(m):
@@ -793,11 +813,16 @@ class TrainEngine:
             self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head),
                                            dev_sd(self.fuse) if self.map_mode else None,
                                            dev_sd(self.memfuse) if self.lane_mode else None)
+        elif self.__dict__.pop("_pdec_fresh", False):
+            pass                    # (built by _packed_decoder in this very step)
         else:
             self._pdec.repack()
+        sites = None
+        if self.drop.active:
+            sites = {n: v for n, v in self.drop.view.items() if n.startswith("dec")}
         ops.decoder_forward(self._pdec, S.eh[self.Le].view(self.B, self.T, self.d), S.pad, start_pos=S.pos[0], ph=self.ph,
-                            map_feat=S.enc_map if self.map_mode else None,
-                            mem_feat=S.enc_lane[:, 0, :].contiguous() if self.lane_mode else None, pred_out=S.pred)
+                            map_feat=S.enc_map_used if self.map_mode else None,
+                            mem_feat=S.enc_lane[:, 0, :].contiguous() if self.lane_mode else None, pred_out=S.pred, dropout=sites)
         S.pos[1:].copy_(S.pred.permute(1, 0, 2))
 
     # ------------------------------------------------------------------ backward

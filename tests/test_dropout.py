@@ -280,3 +280,36 @@ def test_vit_training_step_with_its_dropouts_matches_restatement_autograd():
     for name, prm in ref.m.named_parameters():
         if prm.grad is not None:
             assert rel_err(eng.grad_by_name[name].cpu().numpy(), prm.grad.numpy()) <= 1e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["basic", "map_cnn", "lane_cnn"])
+def test_masked_autoregressive_decode_equals_the_step_by_step_decode(mode):
+    """With dropout the tokens fed back depend on the masks.  At the shipped geometry the inference decoder's launch-per-phase
+    kernels read the step's keep bytes (mmt_decoder_forward_dropout); everywhere else the engine decodes step by step on the
+    stash kernels.  Same seed, same masks: both must give the same positions, loss and gradients."""
+    from multimodal_transformer_amd import ops, training
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _gdev()
+    hp, _, ph = hp_for(mode, False)
+    hp["autoregressive"] = True
+    B = 24
+    model, reg = _ours(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in batch_for(mode, False, B).items()}
+    out = []
+    for masked in (True, False):
+        eng = training.TrainEngine(model, B, t["x_st"].shape[1], ph, seed=21)
+        assert eng.drop.active and eng._ar_decode_takes_masks()
+        if not masked:
+            eng._ar_masks_ok = False
+        eng.set_batch(t["x_st"], t["y_st"], t.get("map"), t.get("lanes"))
+        loss = float(eng.forward())
+        if masked:
+            assert ops.decoder_last_path()[0] == 3          # MMT_PATH_CLUSTER_LAUNCHES4: the kernels that read the masks
+        eng.backward()
+        out.append((loss, eng.predictions().clone(), eng.flat_grad.clone(), eng.drop.pool.clone()))
+    assert torch.equal(out[0][3], out[1][3])                                   # the very same masks
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[1][0])
+    assert rel_err(out[0][1].cpu().numpy(), out[1][1].cpu().numpy()) <= 1e-5
+    assert rel_err(out[0][2].cpu().numpy(), out[1][2].cpu().numpy()) <= 1e-4
