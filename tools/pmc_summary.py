@@ -30,7 +30,7 @@ def main():
     fetch, fcalls = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
     # number of predicts in the run = launches of the encoder kernel
-    enc = next(k for k in fcalls if k.startswith("mmt_encoder_kernel"))
+    enc = next(k for k in fcalls if k.startswith("mmt_encoder_kernel") or k.startswith("mmt_encoder_split_kernel"))
     n_pred = fcalls[enc]
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py",
            "corrections": "KiB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied as 64 B); Infinity-Cache hits included",

@@ -10,4 +10,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout -s KILL 90 rocprofv3 --kernel-trace --stats -d $OUT/kt -o k --output-format csv -- python3 tools/decode_only.py 128 auto 100 > $OUT/kt.log 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $OUT/kt_bench -o k --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs --no-scalings > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $OUT/kt_train -o k --output-format csv -- python3 tools/train_only.py 128 10 0 0 > $OUT/kt_train.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d $OUT/kt_train_dropout -o k --output-format csv -- python3 tools/train_only.py 128 10 1 0 > $OUT/kt_train_dropout.log 2>&1
 echo profiled
