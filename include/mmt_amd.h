@@ -400,14 +400,17 @@ int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long do_bs, long
                       long dq_rs, float *dk, float *dv, long dk_bs, long dk_rs, void *stream);
 /* pos [ph][B][2], y [B][ph][2]: dpos = d/dpos mean_b mean_t ||pos-y||_2; loss_sum (1) += that mean (may be NULL) */
 int mmt_l2_loss_bwd(const float *pos, const float *y, int B, int ph, float *dpos, float *loss_sum, void *stream);
-/* clip_grad_value_(clip) + torch.optim.AdamW over a device-resident table; state_dev = {step, lr} floats on the device */
+/* clip_grad_value_(clip) + torch.optim.AdamW over a device-resident table; state_dev = {step, lr} floats on the device.
+ * guard != NULL: a device float (the step's loss, summed over the data-parallel ranks with the gradients); when it is not
+ * finite the whole update is skipped -- a decode that gave up (NaN positions) must not reach the weights */
 int mmt_adamw_multi(const mmt_adamw_tensor *table_dev, int ntensors, const float *state_dev, float beta1, float beta2,
-                    float eps, float weight_decay, float clip, float grad_scale, void *stream);
+                    float eps, float weight_decay, float clip, float grad_scale, const float *guard, void *stream);
 
 /* x0 = nan_to_num(x_st, nan=0) (Transformer_model.py:47); pad[row] = isnan(x_st[row][1]) (model_utils.py:148-151) */
 int mmt_history_prepare(const float *x_st, int rows, int n_in, float *x0, uint8_t *pad, void *stream);
 /* state[0] += 1 (step count), state[1] *= gamma: ExponentialLR stepped once per batch (train.py:226-227,253-256) */
-int mmt_lr_step(float *state_dev, float gamma, void *stream);
+/* guard as in mmt_adamw_multi: a skipped step leaves state alone and adds 1 to skipped[0] (may be NULL) */
+int mmt_lr_step(float *state_dev, float gamma, const float *guard, float *skipped, void *stream);
 
 /* ---- stand-alone Mlp / teacher-forced pieces -----------------------------------------------------------------
  * softmax over the middle axis of a contiguous (outer, n, inner) tensor: nn.Softmax() of Mlp(mode='classification')

@@ -173,9 +173,9 @@ SIGNATURES = {
                                     C.c_long, C.c_long, C.c_void_p]),
     "mmt_l2_loss_bwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
     "mmt_adamw_multi": (C.c_int, [fptr, C.c_int, fptr, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                  C.c_void_p]),
+                                  fptr, C.c_void_p]),
     "mmt_history_prepare": (C.c_int, [fptr, C.c_int, C.c_int, fptr, fptr, C.c_void_p]),
-    "mmt_lr_step": (C.c_int, [fptr, C.c_float, C.c_void_p]),
+    "mmt_lr_step": (C.c_int, [fptr, C.c_float, fptr, fptr, C.c_void_p]),
     "mmt_softmax_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
     "mmt_cumsum_axis": (C.c_int, [fptr, C.c_long, C.c_int, C.c_long, fptr, C.c_void_p]),
     "mmt_l2_norm": (C.c_int, [fptr, fptr, C.c_long, C.c_int, C.c_long, C.c_long, fptr, C.c_void_p]),

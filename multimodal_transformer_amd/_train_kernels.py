@@ -397,19 +397,23 @@ def adamw_table(entries, device):
     return host.to(device), len(entries)
 
 
-def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, grad_scale):
-    """clip_grad_value_(clip) + torch.optim.AdamW over the table; state = device [step, lr]."""
+def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, grad_scale, guard=None):
+    """clip_grad_value_(clip) + torch.optim.AdamW over the table; state = device [step, lr].  ``guard``: 1-element device
+    tensor; the update is skipped when it is not finite."""
     _dev(table, "table", torch.uint8), _contig2(state, "state", (2,))
+    if guard is not None:
+        _dev(guard, "guard")
     lib = _lib.load()
     _lib.check(lib.mmt_adamw_multi(_p(table), ntensors, _p(state), beta1, beta2, eps, weight_decay, clip, grad_scale,
-                                   _stream()), "mmt_adamw_multi")
+                                   _p(guard), _stream()), "mmt_adamw_multi")
 
 
-def lr_step(state, gamma):
-    """state[0] += 1 (optimizer step count), state[1] *= gamma (ExponentialLR stepped per batch, train.py:226-256)."""
+def lr_step(state, gamma, guard=None, skipped=None):
+    """state[0] += 1 (optimizer step count), state[1] *= gamma (ExponentialLR stepped per batch, train.py:226-256); with a
+    non-finite ``guard`` nothing but ``skipped[0] += 1``."""
     _contig2(state, "state", (2,))
     lib = _lib.load()
-    _lib.check(lib.mmt_lr_step(_p(state), float(gamma), _stream()), "mmt_lr_step")
+    _lib.check(lib.mmt_lr_step(_p(state), float(gamma), _p(guard), _p(skipped), _stream()), "mmt_lr_step")
 
 
 def softmax_axis(x, y, axis):

@@ -972,9 +972,11 @@ __global__ __launch_bounds__(1024) void mmt_l2_loss_bwd_kernel(const float *__re
 // state[0] = step count (float), state[1] = learning rate of group 0 (both live on the device so that a captured
 // graph stays valid while the host scheduler changes them).
 __global__ void mmt_adamw_kernel(const mmt_adamw_tensor *__restrict__ table, int ntensors, const float *__restrict__ state,
-                                 float beta1, float beta2, float eps, float weight_decay, float clip, float grad_scale) {
+                                 float beta1, float beta2, float eps, float weight_decay, float clip, float grad_scale,
+                                 const float *__restrict__ guard) {
   const int t = blockIdx.y;
   if (t >= ntensors) return;
+  if (guard && !isfinite(guard[0])) return;        // a step whose (all-reduced) loss is NaN / inf must not touch the weights
   const mmt_adamw_tensor T = table[t];
   const float step = state[0], lr = state[1] * T.lr_scale;
   const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
@@ -1126,8 +1128,12 @@ __global__ __launch_bounds__(256) void mmt_dropout_apply_kernel(const float *__r
     y[i] = keep[i] ? x[i] * scale : 0.f;
 }
 
-__global__ void mmt_lr_step_kernel(float *state, float gamma) {
+__global__ void mmt_lr_step_kernel(float *state, float gamma, const float *guard, float *skipped) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (guard && !isfinite(guard[0])) {            // the optimizer kernel skipped this step: count it, leave step and lr alone
+      if (skipped) skipped[0] += 1.0f;
+      return;
+    }
     state[0] += 1.0f;
     state[1] *= gamma;
   }
@@ -1347,10 +1353,10 @@ extern "C" int mmt_l2_loss_bwd(const float *pos, const float *y, int B, int ph, 
 }
 
 extern "C" int mmt_adamw_multi(const mmt_adamw_tensor *table_dev, int ntensors, const float *state_dev, float beta1, float beta2,
-                               float eps, float weight_decay, float clip, float grad_scale, void *stream) {
+                               float eps, float weight_decay, float clip, float grad_scale, const float *guard, void *stream) {
   if (!table_dev || !state_dev || ntensors <= 0) return mmt_set_error(MMT_EINVAL, "mmt_adamw_multi: bad arguments");
   hipLaunchKernelGGL(mmt_adamw_kernel, dim3(64, ntensors), dim3(256), 0, (hipStream_t)stream, table_dev, ntensors, state_dev,
-                     beta1, beta2, eps, weight_decay, clip, grad_scale);
+                     beta1, beta2, eps, weight_decay, clip, grad_scale, guard);
   return launch_ok("mmt_adamw_multi");
 }
 
@@ -1382,9 +1388,9 @@ extern "C" int mmt_dropout_apply(const float *x, const uint8_t *keep, float scal
   return launch_ok("mmt_dropout_apply");
 }
 
-extern "C" int mmt_lr_step(float *state_dev, float gamma, void *stream) {
+extern "C" int mmt_lr_step(float *state_dev, float gamma, const float *guard, float *skipped, void *stream) {
   if (!state_dev) return mmt_set_error(MMT_EINVAL, "mmt_lr_step: null state");
-  hipLaunchKernelGGL(mmt_lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, gamma);
+  hipLaunchKernelGGL(mmt_lr_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, gamma, guard, skipped);
   return launch_ok("mmt_lr_step");
 }
 

@@ -520,9 +520,14 @@ class TrainEngine:
         # [0] is the gradient bucket (what the all-reduce and the optimizer see); [1..SPLITK-1] receive the other K-slices of
         # the split weight-gradient GEMMs at the same offsets and are summed into [0] at the end of backward()
         self.SPLITK = 4
+        # one more slot behind the gradients: the step's loss rides in the all-reduce bucket, so that every data-parallel rank
+        # sees the same (summed) value and skips the optimizer together when a rank's step went NaN (Trainer._opt's guard)
+        self.guard_at = total
+        total += 64
         self.grad_total = total
         self.flat_all = torch.zeros(self.SPLITK * total, dtype=torch.float32, device=self.device)
         self.flat_grad = self.flat_all[:total]
+        self.guard = self.flat_grad[self.guard_at:self.guard_at + 1]
         self.grad_of = {}
         self.grad_by_name = {}
         for (name, p), o in zip(named, offs):
@@ -1043,6 +1048,7 @@ class TrainEngine:
             self._wgrad(S.geqkv[l], S.eh[l], sa.in_proj_weight, sa.in_proj_bias)
         self._wgrad(S.geh[0], S.x0, enc.input_fc.weight, enc.input_fc.bias)
         self._sum_split_parts()
+        self.guard.copy_(self.loss)
 
     # ------------------------------------------------------------------ convenience
     def predictions(self):
@@ -1139,6 +1145,9 @@ class Trainer:
         self.use_graph = use_graph
         self._g_fb = self._g_opt = None
         self.steps_done = 0
+        self.skipped = torch.zeros(1, dtype=torch.float32).to(dev)     # optimizer steps skipped because the loss was not finite
+        self._skipped_seen = 0
+        self.check_every = 50                # steps between host looks at ``skipped`` (a device -> host copy)
         self.time_allreduce = False          # bench: HIP events around the gradient all-reduce (allreduce_ms())
         self._ar_events = []
         if self.world > 1:
@@ -1174,8 +1183,26 @@ class Trainer:
 
     def _opt(self):
         K.adamw_step(self.table, self.ntensors, self.state, self.betas[0], self.betas[1], self.eps, self.wd, self.clip,
-                     1.0 / self.world)
-        K.lr_step(self.state, self.gamma)
+                     1.0 / self.world, guard=self.engine.guard)
+        K.lr_step(self.state, self.gamma, guard=self.engine.guard, skipped=self.skipped)
+
+    def skipped_steps(self, check=True):
+        """Optimizer steps skipped so far because the (all-reduced) loss was not finite -- e.g. a one-launch decode that gave up
+        on a shared GPU leaves NaN positions (mmt_decoder_status).  ``check``: on a new skip, query and clear the decoder's
+        fault state (which also keeps the one-launch forms off from now on) and warn."""
+        n = int(self.skipped.item())
+        if check and n > self._skipped_seen:
+            import warnings
+            why = "the loss was not finite"
+            try:
+                ops.decoder_status()
+            except MmtError as e:
+                why = str(e)
+            warnings.warn(f"Trainer: {n - self._skipped_seen} optimizer step(s) skipped, weights untouched: {why}", RuntimeWarning)
+            if self.use_graph:
+                self._g_fb = self._g_opt = None      # re-capture: the decoder form baked into the graph may be the one that failed
+        self._skipped_seen = n
+        return n
 
     def _capture(self):
         # warm-up on a side stream (allocations, library loading), then capture both halves
@@ -1217,6 +1244,8 @@ class Trainer:
         else:
             self._opt()
         self.steps_done += 1
+        if self.check_every and self.steps_done % self.check_every == 0:
+            self.skipped_steps()
         # the kernels wrote the parameters through raw pointers (no torch version bump): drop the packed
         # inference copies so that the next predict() re-packs the updated weights
         for mod in (self.engine.enc, self.engine.dec, self.engine.head, self.engine.cnn, self.engine.fuse, self.engine.lane_enc,

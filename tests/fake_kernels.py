@@ -241,7 +241,9 @@ def adamw_table(entries, device):
     return list(entries), len(entries)
 
 
-def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, grad_scale):
+def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, grad_scale, guard=None):
+    if guard is not None and not bool(torch.isfinite(guard).all()):
+        return
     step, lr0 = float(state[0]), float(state[1])
     for p, g, m, v, s in table:
         lr = lr0 * s
@@ -255,7 +257,11 @@ def adamw_step(table, ntensors, state, beta1, beta2, eps, weight_decay, clip, gr
         p.addcdiv_(m, denom, value=-lr / (1.0 - beta1 ** step))
 
 
-def lr_step(state, gamma):
+def lr_step(state, gamma, guard=None, skipped=None):
+    if guard is not None and not bool(torch.isfinite(guard).all()):
+        if skipped is not None:
+            skipped[0] += 1.0
+        return
     state[0] += 1.0
     state[1] *= gamma
 

@@ -714,3 +714,42 @@ def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
     finally:
         dist.destroy_process_group()
     assert plain[0] == reduced[0] and torch.equal(plain[1], reduced[1])
+
+
+def test_a_step_whose_decode_gave_up_leaves_the_weights_alone():
+    """the autoregressive decode of a training step runs on a one-launch decoder form; if that gives up on a wait
+    (fault injection: mmt_debug_decoder_stall) the positions, the loss and every gradient are NaN.  The optimizer kernels are
+    guarded by the step's loss (which rides in the all-reduce bucket): the step is skipped and counted, the weights and the
+    AdamW state stay as they were, Trainer.skipped_steps() warns and clears the decoder's fault state, the next step trains."""
+    from multimodal_transformer_amd import _lib, ops, training
+    dev = _dev()
+    lib = _lib.load()
+    hp, _, ph = hp_for("basic", False)
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, False, None)
+    B = 32
+    t = {k: torch.from_numpy(v).to(dev) for k, v in batch_for("basic", False, B).items()}
+    tr = training.Trainer(model, B, t["x_st"].shape[1], ph, use_graph=False, dropout=False)
+    tr.check_every = 0
+    tr.step(t["x_st"], t["y_st"])
+    ops.decoder_status()
+    assert tr.skipped_steps() == 0
+    before = [p.detach().clone() for _, p in tr.engine.named_params]
+    state = tr.state.clone()
+    try:
+        lib.mmt_debug_decoder_stall(1)
+        loss = tr.step(t["x_st"], t["y_st"])
+        torch.cuda.synchronize()
+    finally:
+        lib.mmt_debug_decoder_stall(0)
+    assert not bool(torch.isfinite(loss).all())
+    for (_, p), q in zip(tr.engine.named_params, before):
+        assert torch.equal(p.detach(), q)
+    assert torch.equal(tr.state, state)
+    with pytest.warns(RuntimeWarning, match="skipped"):
+        assert tr.skipped_steps() == 1
+    loss = tr.step(t["x_st"], t["y_st"])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss).all()) and tr.skipped_steps() == 1
+    assert any(not torch.equal(p.detach(), q) for (_, p), q in zip(tr.engine.named_params, before))
+    ops.decoder_status()
