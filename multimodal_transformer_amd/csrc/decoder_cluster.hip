@@ -52,12 +52,14 @@ extern "C" int mmt_debug_read_clprof(unsigned long long *host, size_t n) {
 #define PPR_VISITS 192
 __device__ unsigned long long g_pprof[PPR_WGS][PPR_VISITS][16];
 #define PSTAMP(visit, k) do { const int v_ = ((visit) >> 12) * 16 + ((visit) & 4095); if (thread_idx() == 0 && blockIdx.x < PPR_WGS && ((visit) & 4095) < 16 && v_ < PPR_VISITS) g_pprof[blockIdx.x][v_][k] = wall_clock64(); } while (0)
+#define PSTAMPC(visit, k) do { const int v_ = ((visit) >> 12) * 16 + ((visit) & 4095); if (thread_idx() == 0 && blockIdx.x < PPR_WGS && ((visit) & 4095) < 16 && v_ < PPR_VISITS) g_pprof[blockIdx.x][v_][k] = clock64(); } while (0)
 extern "C" int mmt_debug_read_pprof(unsigned long long *host, size_t n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pprof), sizeof(unsigned long long) * n);
 }
 #else
 #define CSTAMP(k) do { } while (0)
 #define PSTAMP(visit, k) do { } while (0)
+#define PSTAMPC(visit, k) do { } while (0)
 #endif
 
 namespace {
@@ -734,11 +736,13 @@ __host__ __device__ __forceinline__ Lin4 lin4(int col_groups, int kquads) {
   return L;
 }
 // sum over the K parts of a column group: lanes that differ in the block bits above lg_cgw
+// (order: across the wave halves, across the row pairs, then inside a row - the static form below halves its registers in
+// the first two steps and must add in the same tree to stay bit-identical)
 __device__ __forceinline__ float kparts_sum(float v, int cgw) {
+  if (cgw <= 8) v = xor32_sum(v);
+  if (cgw <= 4) v = xor16_sum(v);
   if (cgw <= 1) v += dpp_mov<0x124>(v);              // row_ror:4
   if (cgw <= 2) v += dpp_mov<0x128>(v);              // row_ror:8  (after ror:4 this covers all four rotations)
-  if (cgw <= 4) v = xor16_sum(v);
-  if (cgw <= 8) v = xor32_sum(v);
   return v;
 }
 
@@ -872,11 +876,12 @@ __device__ __forceinline__ void weights_issue4(MainRegs4<DH, PHASE> &M, const Cl
     for (int t = 0; t < G4::QMAX1; ++t)
       M.w1[p][t] = bl4s(r1, t < L1.q ? lane_off : OOB, t < L1.q ? (unsigned)((((g * G4::NPART + p) * L1.q + t) * 8 + w) * 1024) : 0u);
   {   // bias: the lanes of the first blocks write the result (block b -> part b in phase A, column group b else)
+    const int bb = b & 3;         // gemm1_4s: in-row block bb of EVERY DPP row writes (row r of the wave = row r of the result)
     int bi;
-    if constexpr (PHASE == PH_A) bi = b * d + g * DH + w * 4 + j;
+    if constexpr (PHASE == PH_A) bi = bb * d + g * DH + w * 4 + j;
     else if constexpr (PHASE == PH_B) bi = g * DH + w * 4 + j;
-    else bi = g * FS + (w * L1.cgw + b) * 4 + j;
-    M.b1 = bl1(mk_rsrc(a.b1), b < (PHASE == PH_C ? L1.cgw : G4::NPART) ? (unsigned)bi * 4u : OOB);
+    else bi = g * FS + (w * L1.cgw + bb) * 4 + j;
+    M.b1 = bl1(mk_rsrc(a.b1), bb < (PHASE == PH_C ? L1.cgw : G4::NPART) ? (unsigned)bi * 4u : OOB);
   }
   {   // second linear: all d output columns, K slice g of out_proj / linear2
     const Lin4 L2 = lin4(d / 4, (PHASE == PH_C ? FS : DH) / 4);
@@ -1295,10 +1300,23 @@ struct Lin4S {
 };
 template <int CGW>
 __device__ __forceinline__ float kparts_sum_s(float v) {
+  if constexpr (CGW <= 8) v = xor32_sum(v);
+  if constexpr (CGW <= 4) v = xor16_sum(v);
   if constexpr (CGW <= 1) v += dpp_mov<0x124>(v);
   if constexpr (CGW <= 2) v += dpp_mov<0x128>(v);
-  if constexpr (CGW <= 4) v = xor16_sum(v);
-  if constexpr (CGW <= 8) v = xor32_sum(v);
+  return v;
+}
+// The same tree for the four rows of one accumulator at a quarter of the instructions: a permlane swap exchanges halves (row
+// pairs) between TWO registers, so one swap + one add finishes two values.  Returns, in DPP row r of the wave, the total of
+// acc[r] (every in-row block holds it, each with the association kparts_sum gives that block).
+template <int CGW>
+__device__ __forceinline__ float kparts_sum_rows(const f32x4 &acc) {
+  static_assert(CGW <= 4, "both cross-row steps are needed");
+  const float u0 = pair32_sum(acc[0], acc[2]);       // lanes 0..31: row 0, lanes 32..63: row 2
+  const float u1 = pair32_sum(acc[1], acc[3]);       //              row 1,               row 3
+  float v = pair16_sum(u0, u1);                      // DPP row r: accumulator row r
+  if constexpr (CGW <= 1) v += dpp_mov<0x124>(v);
+  if constexpr (CGW <= 2) v += dpp_mov<0x128>(v);
   return v;
 }
 template <int DH, int PHASE, int D, int FS>
@@ -1322,20 +1340,15 @@ __device__ __forceinline__ void gemm1_4s(const MainRegs4<DH, PHASE> &M, const fl
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int p = 0; p < G4::NPART; ++p) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[t][e], M.w1[p][t][e], acc[p], 0, 0, 0);
+  // lane (DPP row r, in-row block bb, j) ends with row r of every part; block bb writes part bb (phase A) / column group bb
+  float tot[G4::NPART];
 #pragma unroll
-  for (int p = 0; p < G4::NPART; ++p)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[p][r] = kparts_sum_s<L1::cgw>(acc[p][r]);
+  for (int p = 0; p < G4::NPART; ++p) tot[p] = kparts_sum_rows<L1::cgw>(acc[p]);
+  const int r = b >> 2, bb = b & 3;
   if constexpr (PHASE == PH_A) {
-    if (b < 3) {
-      const f32x4 v = b == 0 ? acc[0] : b == 1 ? acc[G4::NPART > 1 ? 1 : 0] : acc[G4::NPART > 2 ? 2 : 0];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) t1[r * ld1 + b * DH + w * 4 + j] = v[r] + M.b1;
-    }
-  } else if (b < (PHASE == PH_C ? L1::cgw : 1)) {
-    const int col = (w * L1::cgw + b) * 4 + j;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t1[r * ld1 + col] = PHASE == PH_C ? fmaxf(acc[0][r] + M.b1, 0.f) : acc[0][r] + M.b1;
+    if (bb < 3) t1[r * ld1 + bb * DH + w * 4 + j] = (bb == 0 ? tot[0] : bb == 1 ? tot[G4::NPART > 1 ? 1 : 0] : tot[G4::NPART > 2 ? 2 : 0]) + M.b1;
+  } else if (bb < (PHASE == PH_C ? L1::cgw : 1)) {
+    t1[r * ld1 + (w * L1::cgw + bb) * 4 + j] = PHASE == PH_C ? fmaxf(tot[0] + M.b1, 0.f) : tot[0] + M.b1;
   }
 }
 template <int DH, int PHASE, int D, int FS, int AUX>
@@ -1567,6 +1580,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   const int a0 = cluster * 4, na = min(4, a.B - a0);
   const unsigned tag_out = phase_tag(a), tag_in = tag_of_phase((unsigned)a.prof_idx - 1u);
   PSTAMP(visit, 0);
+  PSTAMPC(visit, 12);
   auto kv_request = [&](int cl, int step) {
     const int b0 = cl * 4, nb = min(4, a.B - b0);
 #pragma unroll
@@ -1661,6 +1675,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
                                     a.part_out + ((size_t)cluster * a.H + g0 + h) * 16 * d, tag_out);
   PSTAMP(visit, 5);
   PSTAMP(visit, 6);
+  PSTAMPC(visit, 13);
   return true;
 }
 

@@ -73,6 +73,17 @@ __device__ __forceinline__ float xor32_sum(float v) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return a + b;
 }
+// two values for the price of one: lanes 0..31 get x[l] + x[l + 32], lanes 32..63 get y[l - 32] + y[l]
+// (s_nop 4: x and y may come straight from an MFMA, whose write -> VALU read distance the assembler does not see in here)
+__device__ __forceinline__ float pair32_sum(float x, float y) {
+  asm("s_nop 4\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+// even DPP rows get x[row] + x[row + 1], odd rows y[row - 1] + y[row]
+__device__ __forceinline__ float pair16_sum(float x, float y) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  return x + y;
+}
 __device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
 
 // 4x4 transpose inside every quad of lanes: lane j's register r  <->  lane r's register j

@@ -99,3 +99,16 @@ rows.sort(key=lambda r: r[0])
 base = rows[0][3][0]
 for _, kd, layer, v in rows:
     print(f"  {kd}{layer}: start_wait {us(v[0]-base):7.2f} wait_end {us(v[1]-base):7.2f} loaded {us(v[2]-base):7.2f} g1 {us(v[3]-base):7.2f} att {us(v[4]-base):7.2f} g2 {us(v[5]-base):7.2f} arrived {us(v[6]-base):7.2f}")
+
+# shader clock (s_memtime) against the 100 MHz wall clock over one visit's busy part: the frequency the chip holds in this kernel
+fr = []
+for wg in range(R * per_rep):
+    if role(wg)[1] not in "ABC":
+        continue
+    for s in range(2, 12):
+        for li in range(ncl):
+            v = st[wg, s * 16 + li]
+            if v[6] and v[12] and v[13]:
+                fr.append((v[13] - v[12]) / max(1, (v[6] - v[0])) * 100.0)
+if fr:
+    print(f"shader clock over a visit: median {np.median(fr):.0f} MHz (p10 {np.percentile(fr, 10):.0f}, p90 {np.percentile(fr, 90):.0f})")
