@@ -799,13 +799,16 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
 #pragma unroll
     for (int g = 0; g < 8; ++g) acc += R.p[g];          // unused slots hold zeros
   }
-  const float mu = wave64_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) / (float)a.d;     // lanes beyond d/4 hold zeros
+  // One row per wave: the two totals are wave-uniform (SGPRs), 1/d is a multiplication (exact for the powers of two this path
+  // is built for) and the root is v_rsq_f32 (1 ulp): this sits on the critical path of every one of the decode's 228 hops.
+  const float inv_d = 1.0f / (float)a.d;
+  const float mu = wave64_total((acc[0] + acc[1]) + (acc[2] + acc[3])) * inv_d;     // lanes beyond d/4 hold zeros
   float var = 0.f;
   if (live) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) var += (acc[e] - mu) * (acc[e] - mu);
   }
-  const float rstd = 1.0f / sqrtf(wave64_sum(var) / (float)a.d + MMT_LN_EPS);
+  const float rstd = __builtin_amdgcn_rsqf(wave64_total(var) * inv_d + MMT_LN_EPS);
   if (live) {
     f32x4 y;
 #pragma unroll

@@ -85,6 +85,14 @@ __device__ __forceinline__ float pair16_sum(float x, float y) {
   return x + y;
 }
 __device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+// the same total as ONE wave-uniform value (it lands in an SGPR): row sums, then row_bcast:15 into rows 1 and 3, row_bcast:31
+// into rows 2 and 3, and lane 63 is read out - 7 instructions against the 18 of wave64_sum
+__device__ __forceinline__ float wave64_total(float v) {
+  v = row16_sum(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 
 // 4x4 transpose inside every quad of lanes: lane j's register r  <->  lane r's register j
 __device__ __forceinline__ void quad_transpose(f32x4 &a, int j) {
