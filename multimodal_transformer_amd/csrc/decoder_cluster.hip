@@ -381,6 +381,52 @@ __device__ __forceinline__ void embed_token(const ClArgs &a, int cluster, const 
   }
 }
 
+// the same with input_fc resident (the pipeline's head workgroups embed one token per visit): wave w owns slabs w and w + 8
+// (d <= 256); pe[] = this step's positional-encoding values of the lane's two columns.  Only rows 0..3 are written.
+struct EmbedW {
+  f32x4 wv[2];
+  float b[2];
+};
+__device__ __forceinline__ void embed_load(EmbedW &E, const ClArgs &a) {
+  const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int slab = w + CNW * j;
+    E.wv[j] = bl4(mk_rsrc(a.input_fc.w), slab < D16 ? (unsigned)(slab * 64 + lane) * 16u : OOB);
+    E.b[j] = bl1(mk_rsrc(a.input_fc.b), slab < D16 ? (unsigned)(slab * 16 + (lane & 15)) * 4u : OOB);
+  }
+}
+__device__ __forceinline__ void embed_pe(float (&pe)[2], const ClArgs &a, int s) {
+  const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int slab = w + CNW * j;
+    pe[j] = bl1(mk_rsrc(a.pe + (size_t)s * a.d), slab < D16 ? (unsigned)(slab * 16 + (lane & 15)) * 4u : OOB);
+  }
+}
+__device__ __forceinline__ void embed_token_res(const ClArgs &a, const EmbedW &E, const float (&pe)[2], const float *tok, float *xs, int ldx) {
+  const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
+  const f32x4 xv = *reinterpret_cast<const f32x4 *>(tok + (lane & 15) * LDTOK + (lane >> 4) * 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int slab = w + CNW * j;
+    if (slab < D16) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[e], E.wv[j][e], acc, 0, 0, 0);
+      const float add = E.b[j] + pe[j];
+      if (lane < 16) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float y = acc[rr] + add;
+          if (a.tagged) y = tag1(y, (unsigned)a.s & TAG_MASK);
+          xs[rr * ldx + slab * 16 + lane] = y;
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void small_load(KsW<4, 1> &r, const mmt_linear &lin) {
   ks_load<4, 1>(r, lin.w, round16(lin.k) >> 4, round16(lin.n) >> 4, [](int s) { return s; });
 }
@@ -1748,11 +1794,21 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
   KsW<4, 1> sm0 = {};
   ks_load<4, CPW>(wo, a.output_fc.w, K16, round16(a.n_out) >> 4, [](int s) { return s; });     // resident for the whole decode
   if (!a.tgt) small_load(sm0, a.chain[0]);
+  EmbedW emb;
+  embed_load(emb, a);
+  // once: the head's tiles and the token tile hold finite values (their padding columns must stay zero: nothing else writes
+  // them) and rows 4..15 of the head's input tile are zero (a visit writes rows 0..3 only)
+  for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) S.ha[i] = 0.f;
+  if (tid >= 256)
+    for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
+      *reinterpret_cast<f32x4 *>(S.xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma clang loop unroll(disable)
   for (int s = 0; s < f.a.ph; ++s) {
     const unsigned p = (unsigned)(s * NP);           // the phase this step's first stage runs as; the head consumes phase p - 1
     a.s = s;
     a.prof_idx = (int)p;
+    float pe[2];
+    embed_pe(pe, a, s);
     const unsigned p_last = (unsigned)(NP * f.a.ph - 1);
     const size_t rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
     a.part_in = f.part[(p + 1) & 1] + rb_in;
@@ -1770,10 +1826,6 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         R.gam = bl4(mk_rsrc(a.red_ln.g), co);
         R.bet = bl4(mk_rsrc(a.red_ln.b), co);
       }
-      for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) S.ha[i] = 0.f;      // the head's tiles and the token tile: finite
-      if (tid >= 256)                                                                   // rows 4..15 of the head's input tile
-        for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
-          *reinterpret_cast<f32x4 *>(S.xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (red_wave) (void)poll_rows<false>(R, a, f.x0buf, m, tag_of_phase(p - 1u), ps);
       PSTAMP(s * 4096 + li, 1);
       __syncthreads();
@@ -1787,13 +1839,13 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         }
       __syncthreads();
       PSTAMP(s * 4096 + li, 4);
-      embed_token<false>(a, m, S.tok, S.xs, ldx, false);      // rows tagged s & 1
+      embed_token_res(a, emb, pe, S.tok, S.xs, ldx);         // rows tagged s & 1
       __syncthreads();
       PSTAMP(s * 4096 + li, 5);
       if (wave_id() < 4 && lane_id() < (d >> 2))       // the embedded token, write-through, 16 bytes per lane
         bs4x<AUX_SC1>(mk_rsrc(f.x0buf + ((size_t)m * 4 + wave_id()) * d), (unsigned)lane_id() * 16u,
                       *reinterpret_cast<const f32x4 *>(S.xs + wave_id() * ldx + 4 * lane_id()));
-      __syncthreads();                                  // xs is rewritten by the next visit
+      // (no barrier here: xs and tok are next written behind the barrier that follows the next visit's poll)
       PSTAMP(s * 4096 + li, 6);
     }
   }
