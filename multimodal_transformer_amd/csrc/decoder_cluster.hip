@@ -169,13 +169,22 @@ __device__ __forceinline__ bool ks_elem(int it, int S, int &row, int &col) {
 template <int CPW, int NIT, class Epi>
 __device__ __forceinline__ void ks_reduce(const float *red, int K16, int S, Epi epi) {
   const int nwu = min(CNW, (K16 + CPW - 1) / CPW);
+  // every LDS read of every pass is issued before the first add (a loop over the nwu tiles pays one LDS round trip per
+  // tile and pass); the tiles of waves >= nwu were never written and are read but not added.  Same order of additions.
+  float v[NIT][CNW];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = thread_idx() + CNT * it, s = min(idx >> 8, KS_SMAX - 1), rem = idx & 255;
+#pragma unroll
+    for (int w = 0; w < CNW; ++w) v[it][w] = red[(w * KS_SMAX + s) * 256 + rem];
+  }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int idx = thread_idx() + CNT * it;
     if (idx < S * 256) {
-      const int s = idx >> 8, rem = idx & 255;
       float sum = 0.f;
-      for (int w = 0; w < nwu; ++w) sum += red[(w * KS_SMAX + s) * 256 + rem];
+#pragma unroll
+      for (int w = 0; w < CNW; ++w) sum = w < nwu ? sum + v[it][w] : sum;
       int row, col;
       ks_elem(it, S, row, col);
       epi(row, col, sum, it);
@@ -737,10 +746,20 @@ __global__ __launch_bounds__(CNT) void mmt_dec_phase_kernel(ClArgs a) {
 #pragma unroll
       for (int e = 0; e < DPL; ++e) o[e] = 0.f;
       const int nk = ar < na ? nkeys : 0;
-      for (int j = 0; j < nk; ++j) {
-        const float pj = ps[ar * 16 + j];
+      // all LDS reads in flight at once, then the same fused multiply-adds in the same order (a loop with a run-time trip
+      // count pays one LDS round trip per key); rows beyond nk hold stale bits and are never multiplied
+      typedef float vrow __attribute__((ext_vector_type(DPL)));
+      f32x4 pr[KMAX / 4];
+      vrow vv[KMAX];
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, Vs[(ar * KMAX + j) * LDK + l16 * DPL + e], o[e]);
+      for (int c = 0; c < KMAX / 4; ++c) pr[c] = *reinterpret_cast<const f32x4 *>(ps + ar * 16 + 4 * c);
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) vv[j] = *reinterpret_cast<const vrow *>(Vs + (ar * KMAX + j) * LDK + l16 * DPL);
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const float pj = pr[j >> 2][j & 3];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = j < nk ? fmaf(pj, vv[j][e], o[e]) : o[e];
       }
 #pragma unroll
       for (int e = 0; e < DPL; ++e) ob[ar * LDO + l16 * DPL + e] = o[e];
@@ -1205,10 +1224,20 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
 #pragma unroll
       for (int e = 0; e < DPL; ++e) o[e] = 0.f;
       const int nk = ar < na ? nglob : 0;
-      for (int j = 0; j < nk; ++j) {
-        const float pj = ps[ar * 16 + j];
+      {   // all LDS reads in flight at once, then the same fused multiply-adds in the same order (as attend4)
+        typedef float vrow __attribute__((ext_vector_type(DPL)));
+        f32x4 pr[KMAX / 4];
+        vrow vv[KMAX];
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, Vs[(ar * KMAX + j) * LDK + l16 * DPL + e], o[e]);
+        for (int c = 0; c < KMAX / 4; ++c) pr[c] = *reinterpret_cast<const f32x4 *>(ps + ar * 16 + 4 * c);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) vv[j] = *reinterpret_cast<const vrow *>(Vs + (ar * KMAX + j) * LDK + l16 * DPL);
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          const float pj = pr[j >> 2][j & 3];
+#pragma unroll
+          for (int e = 0; e < DPL; ++e) o[e] = j < nk ? fmaf(pj, vv[j][e], o[e]) : o[e];
+        }
       }
       if (PHASE == PH_A && ar < na) {
         const float pj = ps[ar * 16 + nglob];
@@ -1992,11 +2021,43 @@ int dev_ncu(int dev) {
 
 // Agents per cluster: 16 fills the MFMA tile; small batches use fewer so that more CUs share the work (every
 // workgroup takes in its weight slice at ~50 GB/s, and the partials it sums scale with the rows).
-int cluster_rows(int B, int H) {
+bool mfma4_fits(const mmt_decoder *dec);
+enum { ONE_LAUNCH_NONE = 0, ONE_LAUNCH_FUSED = 1, ONE_LAUNCH_PIPE = 2 };
+struct PipeGeom {
+  int R, NHW, grid;     // replicas of the pipeline, head workgroups per replica, workgroups in all
+  float *x0buf;
+};
+// Replicas / head workgroups that fit on `ncu` CUs (one workgroup per CU); R = 0: the pipeline does not fit.
+PipeGeom pipe_geom(int L, int H, int NC, int ncu) {
+  PipeGeom g = {0, 0, 0, nullptr};
+  if (H < 2 || (H & 1)) return g;
+  const int per_stage = L * (2 * H + H / 2);
+  g.R = std::min(NC, ncu / (per_stage + 1));
+  if (g.R < 1) return g;
+  const int per_rep_clusters = (NC + g.R - 1) / g.R;
+  g.NHW = std::max(1, std::min(std::min((ncu - g.R * per_stage) / g.R, 4), per_rep_clusters));
+  g.grid = g.R * (per_stage + g.NHW);
+  return g;
+}
+
+// static conditions of the pipeline form (the run-time ones - occupancy, a device that has timed out before - are checked
+// per call; where they fail the 4-agent launch-per-phase kernels run)
+bool pipe_applies(const mmt_decoder *dec, int NC, int ncu) {
+  if (dec_env().no_fused || dec_env().no_pipe || !mfma4_fits(dec)) return false;
+  if (dec->d_model != 256 || dec->d_ff != 64 * dec->nhead) return false;
+  return pipe_geom(dec->nlayers, dec->nhead, NC, ncu).R >= 1;
+}
+
+// The pipeline kernel's grid does not grow with the batch, so beyond the batch whose 4-agent clusters fill the chip one per
+// workgroup it runs in throughput mode (about 5 us per cluster visit and stage): B = 160 / 192 / 256 decode in 1.26 / 1.50 / 1.95 ms
+// against 2.1 ms on the 16-row launch-per-phase kernels, B = 384 / 512 in 2.87 / 3.80 against 2.4 / 2.5.
+constexpr int PIPE_MAX_B = 256;
+int cluster_rows(const mmt_decoder *dec, int B) {
   if (dec_env().cluster_rows) return dec_env().cluster_rows;
-  const int ncu = dev_ncu(cur_dev());
+  const int ncu = dev_ncu(cur_dev()), H = dec->nhead;
   int rc = 16;
   while (rc > 4 && ((B + rc / 2 - 1) / (rc / 2)) * H <= ncu) rc /= 2;
+  if (rc > 4 && B <= PIPE_MAX_B && pipe_applies(dec, (B + 3) / 4, ncu)) rc = 4;
   return rc;
 }
 
@@ -2127,29 +2188,11 @@ bool mmt_cluster_decoder_supports(const mmt_decoder *dec, int map_dim, bool auto
 }
 
 size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
-  const int RC = cluster_rows(B, dec->nhead);
+  const int RC = cluster_rows(dec, B);
   const size_t NC = (B + RC - 1) / RC, d = dec->d_model;
   // + the fused kernel's time-out word and per-cluster arrival counters, one 128-byte line each (32 floats of slack to align them)
   // ... and the pipeline kernel's token buffer [NC][4][d]
   return NC * 16 * d * (2 * (size_t)dec->nhead + 2) + (dec->has_mem_fusion ? (size_t)B * T * d : 0) + 64 + (NC + 2) * 32 + NC * 4 * d + 32;
-}
-
-enum { ONE_LAUNCH_NONE = 0, ONE_LAUNCH_FUSED = 1, ONE_LAUNCH_PIPE = 2 };
-struct PipeGeom {
-  int R, NHW, grid;     // replicas of the pipeline, head workgroups per replica, workgroups in all
-  float *x0buf;
-};
-// Replicas / head workgroups that fit on `ncu` CUs (one workgroup per CU); R = 0: the pipeline does not fit.
-static PipeGeom pipe_geom(int L, int H, int NC, int ncu) {
-  PipeGeom g = {0, 0, 0, nullptr};
-  if (H < 2 || (H & 1)) return g;
-  const int per_stage = L * (2 * H + H / 2);
-  g.R = std::min(NC, ncu / (per_stage + 1));
-  if (g.R < 1) return g;
-  const int per_rep_clusters = (NC + g.R - 1) / g.R;
-  g.NHW = std::max(1, std::min(std::min((ncu - g.R * per_stage) / g.R, 4), per_rep_clusters));
-  g.grid = g.R * (per_stage + g.NHW);
-  return g;
 }
 
 #define CL_CHECK(what)                                                                     \
@@ -2391,7 +2434,7 @@ extern "C" int mmt_debug_decoder_stall(int on) {
 
 // Same contract as mmt_decoder_forward (arguments already validated there).
 bool mmt_cluster_decoder_dropout_ok(const mmt_decoder *dec, int B) {
-  return cluster_rows(B, dec->nhead) == 4 && mfma4_fits(dec);
+  return cluster_rows(dec, B) == 4 && mfma4_fits(dec);
 }
 
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
@@ -2400,7 +2443,7 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
                                 int allow_fused, void *stream, const mmt_decoder_dropout *drop) {      // 0: launch per phase, 1: fused kernel, 2: pipeline, 3: best
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d_model, H = dec->nhead, L = dec->nlayers;
-  const int RC = cluster_rows(B, H), NC = (B + RC - 1) / RC;
+  const int RC = cluster_rows(dec, B), NC = (B + RC - 1) / RC;
   if (drop) {
     if (!mmt_cluster_decoder_dropout_ok(dec, B) || tgt)
       return mmt_set_error(MMT_EINVAL, "mmt_decoder_forward_dropout: only the autoregressive decode on the 4-agent-cluster kernels "

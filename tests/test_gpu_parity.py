@@ -190,6 +190,12 @@ def test_batch_invariance_and_determinism():
     assert torch.equal(full, torch.cat(parts))
     odd = model.predict(x[:37].contiguous(), x_st[:37].contiguous(), None, None, None, 12)[0]
     assert torch.equal(full[:37], odd)
+    # 129..256 agents: still 4-agent clusters, the weight-stationary pipeline in throughput mode (more clusters than stages)
+    # (the encoder runs on other tiles there - one workgroup per agent tile instead of two: same arithmetic per row, other
+    # summation order - so rows agree to rounding, not bit for bit; rows 128.. repeat rows 0..71 and must equal them exactly)
+    twice = model.predict(torch.cat([x, x[:72]]), torch.cat([x_st, x_st[:72]]), None, None, None, 12)[0]
+    assert rel_err(twice[:128].cpu().numpy(), full.cpu().numpy()) <= 1e-6
+    assert torch.equal(twice[128:], twice[:72])
 
 
 def _flat(out):
@@ -214,7 +220,7 @@ def test_fused_decoder_is_bit_identical_to_launch_per_phase():
         hp = make_hyperparams(mode, history=8, horizon=12)
         model, reg = _model(hp, dev)
         apply_recipe(reg.model_dict, seed=0)
-        for B in (128, 37, 3):
+        for B in (128, 37, 3) + ((256, 203) if mode == "basic" else ()):      # > 128: the pipeline in throughput mode
             x, x_st, _, _, lanes, maps = _to(make_batch(B, 8, 12, seed=B, with_map=(mode == "map_cnn"),
                                                         with_lanes=(mode == "lane_cnn")), dev)
             ops.decoder_select("cluster_launches")
