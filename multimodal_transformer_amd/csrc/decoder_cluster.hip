@@ -1581,7 +1581,12 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
 
 // attention of one head for the 4 agents of a cluster, on ONE wave: one (agent, key) pair per lane; phase A takes the key / value
 // of this step from t1 (same arithmetic, same order as phase4_body)
-template <int DH, int PHASE>
+#ifndef PIPE_ATT_ZEROED
+#define PIPE_ATT_ZEROED true
+#endif
+// ZEROED: the staging tiles were zeroed once and only rows that hold keys are ever written, so rows beyond the keys are finite
+// zeros and meet probabilities that are zeros: no select per key (16 lane masks = 32 spilled SGPRs in this kernel)
+template <int DH, int PHASE, bool ZEROED = false>
 __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const float *t1, int ld1, const float *Ks, const float *Vs,
                                         float *ps, float *ob, int visit = 0) {
   constexpr int LDK = DH + 4;
@@ -1633,7 +1638,7 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
   for (int j = 0; j < KMAX; ++j) {
     const float pj = pr[j >> 2][j & 3];
 #pragma unroll
-    for (int e = 0; e < DPL; ++e) o[e] = j < nk ? fmaf(pj, vv[j][e], o[e]) : o[e];
+    for (int e = 0; e < DPL; ++e) o[e] = (ZEROED || j < nk) ? fmaf(pj, vv[j][e], o[e]) : o[e];
   }
   if (PHASE == PH_A && ar < na) {
     const float pj = ps[ar * 16 + nglob];
@@ -1728,7 +1733,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   if constexpr (PHASE != PH_C) {
     if (wave_id() < NH) {
       const int h = wave_id();
-      attend4<DH, PHASE>(a, na, pad_now, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
+      attend4<DH, PHASE, PIPE_ATT_ZEROED>(a, na, pad_now, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
                          S.ob + h * 4 * LDO, visit);
     } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read back by this workgroup only)
       const int i = tid - 256;
@@ -1774,6 +1779,11 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
   for (int h = 0; h < NH; ++h) {
     M[h] = {};
     weights_issue4<DH, PHASE>(M[h], a, g0 + h);      // ONCE: the slice stays in registers for the whole decode
+  }
+  if constexpr (PHASE != PH_C) {      // attend4<ZEROED>: rows of the K/V staging tiles that never hold a key read as zeros
+    constexpr int LDK = DH + 4;
+    for (int i = thread_idx(); i < 2 * (2 * 4 * KMAX * LDK); i += CNT) S.Ks[i] = 0.f;       // Ks and Vs are adjacent
+    __syncthreads();
   }
   const int NP = 3 * f.nlayers, k = 3 * layer + PHASE;
   const bool loadx = PHASE == PH_A && layer == 0;    // the first stage takes the embedded token as it is (no reduction, no LayerNorm)
