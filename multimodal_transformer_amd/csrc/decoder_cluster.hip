@@ -552,7 +552,7 @@ __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na
         ks_reduce<1, 2>(red, k16, s16, [&](int r, int c, float v, int) { alt[r * LDO + c] = c < n ? v + (bias ? bias[c] : 0.f) : 0.f; });
         __syncthreads();
         if (a.chain_ln[i].g) {
-          layer_norm_rows<true>(alt, LDO, 16, n, a.chain_ln[i]);
+          layer_norm_rows<true>(alt, LDO, a.RC, n, a.chain_ln[i]);      // rows beyond the cluster: bias values, never read
           __syncthreads();
         }
         float *t = cur;
@@ -1481,14 +1481,15 @@ struct PipeArgs {
 constexpr int PIPE_MAXPOS = 16;                // clusters whose last positions a head workgroup keeps in LDS (others: pred_st)
 
 struct PipeLds {
-  float *xs, *red, *ha, *hb, *tok, *t1, *ob, *ps, *Ks, *Vs, *pos;
+  float *xs, *red, *ha, *hb, *tok, *t1, *ob, *ps, *Ks, *Vs, *pos, *prm;
   int *abort;
 };
+constexpr int PIPE_PRM = 64 * (1 + 3 * CHAIN_MAX);      // head workgroups: biases and LayerNorm vectors of the small linears
 template <int DH>
 __host__ __device__ __forceinline__ size_t pipe_lds_floats(int d) {
   constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
   return (size_t)16 * (d + MMT_PAD) + CNW * KS_SMAX * 256 + 2 * 16 * LDO + 16 * LDTOK + 2 * 4 * LD1 + 2 * 4 * LDO + 256 +
-         2 * (2 * 4 * KMAX * LDK) + PIPE_MAXPOS * 64;
+         2 * (2 * 4 * KMAX * LDK) + PIPE_MAXPOS * 64 + PIPE_PRM;
 }
 template <int DH>
 __device__ __forceinline__ PipeLds pipe_lds(float *smem, int d) {
@@ -1506,6 +1507,7 @@ __device__ __forceinline__ PipeLds pipe_lds(float *smem, int d) {
   L.Ks = L.ps + 256;                             // [2][4][KMAX][LDK]
   L.Vs = L.Ks + 2 * 4 * KMAX * LDK;
   L.pos = L.Vs + 2 * 4 * KMAX * LDK;             // [PIPE_MAXPOS][4][16]
+  L.prm = L.pos + PIPE_MAXPOS * 64;              // [PIPE_PRM]
   return L;
 }
 
@@ -1835,6 +1837,25 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
   if (!a.tgt) small_load(sm0, a.chain[0]);
   EmbedW emb;
   embed_load(emb, a);
+  {   // the biases and LayerNorm vectors the head's epilogues read, copied into LDS once (every one of them was a dependent L2
+      // round trip per visit on the decode's critical path)
+    int off = 0;
+    auto stage = [&](const float *&p, int n) {
+      if (p) {
+        for (int i = tid; i < n; i += CNT) S.prm[off + i] = p[i];
+        p = S.prm + off;
+      }
+      off += 64;
+    };
+    stage(a.output_fc.b, a.n_out);
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX; ++i)
+      if (i < a.n_chain) {
+        stage(a.chain[i].b, a.chain[i].n);
+        stage(a.chain_ln[i].g, a.chain[i].n);
+        stage(a.chain_ln[i].b, a.chain[i].n);
+      }
+  }
   // once: the head's tiles and the token tile hold finite values (their padding columns must stay zero: nothing else writes
   // them) and rows 4..15 of the head's input tile are zero (a visit writes rows 0..3 only)
   for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) S.ha[i] = 0.f;
