@@ -843,11 +843,28 @@ __device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int 
   R.gam = bl4(mk_rsrc(a.red_ln.g), co);
   R.bet = bl4(mk_rsrc(a.red_ln.b), co);
 }
-template <int AUX = AUX_PLAIN, bool DROP = false>
+// PAIRS (the reduction that follows the cross-attention phase): the parts are added two by two, each pair sum carrying the
+// producing phase's tag - exactly what the pipeline kernel's cross-attention workgroups, which own two heads each, hand over
+// as ONE pre-summed part (half the rows for its consumers to load); the forms stay bit-identical.
+template <int AUX = AUX_PLAIN, bool DROP = false, bool PAIRS = false>
 __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res,
                                                bool tag_rows = true) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
+  f32x4 part[PAIRS ? 4 : 8];
+  if constexpr (PAIRS) {
+    const unsigned tag_in = tag_of_phase((unsigned)a.prof_idx - 1u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      part[k] = R.p[2 * k] + R.p[2 * k + 1];
+      if (a.tagged) part[k] = tag4(part[k], tag_in);
+      if (2 * k >= a.H) part[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) part[g] = R.p[g];
+  }
+  constexpr int NPT = PAIRS ? 4 : 8;
   f32x4 acc = R.res + R.bias;
   bool dropped = false;
   if constexpr (DROP) {            // res + keep * (bias + sum of the parts)
@@ -855,14 +872,14 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
     if (a.dk_red && live && ag < a.B) {
       f32x4 t = R.bias;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) t += R.p[g];
+      for (int g = 0; g < NPT; ++g) t += part[g];
       acc = R.res + keep4(a.dk_red, (size_t)ag * a.d + 4 * q, a.ds_red) * t;
       dropped = true;
     }
   }
   if (!dropped) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) acc += R.p[g];          // unused slots hold zeros
+    for (int g = 0; g < NPT; ++g) acc += part[g];       // unused slots hold zeros
   }
   // One row per wave: the two totals are wave-uniform (SGPRs), 1/d is a multiplication (exact for the powers of two this path
   // is built for) and the root is v_rsq_f32 (1 ulp): this sits on the critical path of every one of the decode's 228 hops.
@@ -1149,7 +1166,7 @@ __device__ __forceinline__ bool phase4_body(const ClArgs &a, int cluster, int g,
   }
 
   // ---- 2. input of this sub-layer
-  if (red_wave) reduce4_finish<AUX, DROP>(R, a, cluster, xs, ldx, g == 0 && !HEAD, !HEAD);
+  if (red_wave) reduce4_finish<AUX, DROP, PHASE == PH_C>(R, a, cluster, xs, ldx, g == 0 && !HEAD, !HEAD);
   if constexpr (HEAD) {
     head_step<CPW>(a, g, a0, na, xs, ldx, red, ha, hb, tok, wo, sm_cur, FUSED ? pos : nullptr);
     main_issue4<DH, PHASE, AUX>(M, a, a0, na, g);
@@ -1429,6 +1446,39 @@ __device__ __forceinline__ void gemm1_4s(const MainRegs4<DH, PHASE> &M, const fl
     t1[r * ld1 + (w * L1::cgw + bb) * 4 + j] = PHASE == PH_C ? fmaxf(tot[0] + M.b1, 0.f) : tot[0] + M.b1;
   }
 }
+// the accumulators of one second linear, K parts summed (every lane of a column group's blocks holds the total)
+template <int DH, int PHASE, int D, int FS>
+__device__ __forceinline__ f32x4 gemm2_4s_acc(const MainRegs4<DH, PHASE> &M, const float *x2, int ld2) {
+  typedef Geom4<PHASE> G4;
+  constexpr int K2q = (PHASE == PH_C ? FS : DH) / 4;
+  typedef Lin4S<D / 4, K2q> L2;
+  static_assert(L2::q <= G4::QMAX2, "second linear exceeds the register tile");
+  const int lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const int kq0 = (b >> L2::lg_cgw) * L2::q;
+  const float *xr = x2 + j * ld2;
+  f32x4 xv[L2::q];
+#pragma unroll
+  for (int t = 0; t < L2::q; ++t) xv[t] = *reinterpret_cast<const f32x4 *>(xr + 4 * min(kq0 + t, K2q - 1));
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < L2::q; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xv[t][e], M.w2[t][e], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = kparts_sum_s<L2::cgw>(acc[r]);
+  return acc;
+}
+// two heads of one workgroup (cross attention): ONE part = tag(tag(part of head g0) + tag(part of head g0 + 1)), in the slot of g0
+template <int DH, int PHASE, int D, int FS, int AUX>
+__device__ __forceinline__ void gemm2_4s_pair(const MainRegs4<DH, PHASE> (&M)[2], const float *x2, int ld2, int hstride, float *part,
+                                              unsigned tag) {
+  typedef Lin4S<D / 4, (PHASE == PH_C ? FS : DH) / 4> L2;
+  const int w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
+  const f32x4 a0 = gemm2_4s_acc<DH, PHASE, D, FS>(M[0], x2, ld2), a1 = gemm2_4s_acc<DH, PHASE, D, FS>(M[1], x2 + hstride, ld2);
+  f32x4 acc = tag4(tag4(a0, tag) + tag4(a1, tag), tag);
+  quad_transpose(acc, j);
+  bs4x<AUX>(mk_rsrc(part), b < L2::cgw ? (unsigned)(j * D + (w * L2::cgw + b) * 4) * 4u : OOB, acc);
+}
 template <int DH, int PHASE, int D, int FS, int AUX>
 __device__ __forceinline__ void gemm2_4s(const MainRegs4<DH, PHASE> &M, const float *x2, int ld2, float *part, unsigned tag) {
   typedef Geom4<PHASE> G4;
@@ -1532,7 +1582,9 @@ __device__ __forceinline__ void pipe_give_up(const PipeSync &ps, int phase, int 
 // the steady state the rows are there or land within a round trip); after a miss the wave probes ONE 64-byte piece (four lanes)
 // of the last partial row, with s_sleep, until it shows the tag - idle stages must not load the memory system - and then takes
 // everything again.  Returns false when it gave up (wave-uniform).
-template <bool X0>
+// GS: stride of the part slots that exist (2 behind the cross-attention stage, whose workgroups hand over one pre-summed part
+// for their two heads, in the slot of the even head)
+template <bool X0, int GS = 1>
 __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const float *x0buf, int cluster, unsigned tag, const PipeSync &ps) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
@@ -1547,9 +1599,13 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
     bool ok = !live || tag_ok(R.res, tag);
     if constexpr (!X0) {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        R.p[g] = bl4x<AUX_SC1>(pp, g < a.H ? co : OOB, g < a.H ? g * gstride : 0u);
-        ok = ok && (g >= a.H || !live || tag_ok(R.p[g], tag));
+      for (int g = 0; g < 8 / GS; ++g) {
+        R.p[g] = bl4x<AUX_SC1>(pp, g * GS < a.H ? co : OOB, g * GS < a.H ? g * GS * gstride : 0u);
+        ok = ok && (g * GS >= a.H || !live || tag_ok(R.p[g], tag));
+      }
+      if constexpr (GS > 1) {
+#pragma unroll
+        for (int g = 8 / GS; g < 8; ++g) R.p[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
     if (__all(ok)) return true;
@@ -1565,7 +1621,7 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
     for (unsigned n = 0;; ++n) {         // thin polling
       __builtin_amdgcn_s_sleep(2);
       asm volatile("" ::: "memory");
-      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, (unsigned)(a.H - 1) * gstride);
+      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, (unsigned)(a.H - GS) * gstride);
       if (__all(q >= 4 || tag_ok(v, tag))) break;
       if ((n & 15u) == 15u) {
         const bool late = wall_clock64() - t0 > PIPE_WAIT_TICKS;
@@ -1692,7 +1748,8 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
       R.gam = bl4(mk_rsrc(a.red_ln.g), co);
       R.bet = bl4(mk_rsrc(a.red_ln.b), co);
     }
-    got = loadx ? poll_rows<true>(R, a, x0buf, cluster, (unsigned)a.s & TAG_MASK, ps) : poll_rows<false>(R, a, x0buf, cluster, tag_in, ps);
+    got = loadx ? poll_rows<true>(R, a, x0buf, cluster, (unsigned)a.s & TAG_MASK, ps)
+                : poll_rows<false, PHASE == PH_C ? 2 : 1>(R, a, x0buf, cluster, tag_in, ps);
   }
   (void)got;                                           // a wave that gave up has raised the abort flag
   PSTAMP(visit, 1);
@@ -1754,10 +1811,14 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   }
   PSTAMP(visit, 4);
   // ---- 5. K-slices of the output projection: one tagged partial [4][d] per head / slice, write-through, nothing to wait for
+  if constexpr (NH == 2) {
+    gemm2_4s_pair<DH, PHASE, D, FS, AUX>(M, S.ob, LDO, 4 * LDO, a.part_out + ((size_t)cluster * a.H + g0) * 16 * d, tag_out);
+  } else {
 #pragma unroll
-  for (int h = 0; h < NH; ++h)
-    gemm2_4s<DH, PHASE, D, FS, AUX>(M[h], PHASE == PH_C ? S.t1 : S.ob + h * 4 * LDO, PHASE == PH_C ? LD1 : LDO,
-                                    a.part_out + ((size_t)cluster * a.H + g0 + h) * 16 * d, tag_out);
+    for (int h = 0; h < NH; ++h)
+      gemm2_4s<DH, PHASE, D, FS, AUX>(M[h], PHASE == PH_C ? S.t1 : S.ob + h * 4 * LDO, PHASE == PH_C ? LD1 : LDO,
+                                      a.part_out + ((size_t)cluster * a.H + g0 + h) * 16 * d, tag_out);
+  }
   PSTAMP(visit, 5);
   PSTAMP(visit, 6);
   PSTAMPC(visit, 13);
