@@ -881,8 +881,8 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
 #pragma unroll
     for (int g = 0; g < NPT; ++g) acc += part[g];       // unused slots hold zeros
   }
-  // One row per wave: the two totals are wave-uniform (SGPRs), 1/d is a multiplication (exact for the powers of two this path
-  // is built for) and the root is v_rsq_f32 (1 ulp): this sits on the critical path of every one of the decode's 228 hops.
+  // One row per wave: the two totals are wave-uniform (SGPRs) and 1/d is a multiplication (exact for the powers of two this
+  // path is built for): this sits on the critical path of every one of the decode's 228 hops.
   const float inv_d = 1.0f / (float)a.d;
   const float mu = wave64_total((acc[0] + acc[1]) + (acc[2] + acc[3])) * inv_d;     // lanes beyond d/4 hold zeros
   float var = 0.f;
@@ -890,7 +890,9 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
 #pragma unroll
     for (int e = 0; e < 4; ++e) var += (acc[e] - mu) * (acc[e] - mu);
   }
-  const float rstd = __builtin_amdgcn_rsqf(wave64_total(var) * inv_d + MMT_LN_EPS);
+  // (1 / sqrt stays IEEE: v_rsq_f32's 1 ulp, applied 228 times in a row, moved the full-size training gradients from 4e-4 to
+  // 9e-4 of the reference's - measured; it would save 1.1 % of the decode)
+  const float rstd = 1.0f / sqrtf(wave64_total(var) * inv_d + MMT_LN_EPS);
   if (live) {
     f32x4 y;
 #pragma unroll
