@@ -283,7 +283,7 @@ def test_vit_training_step_with_its_dropouts_matches_restatement_autograd():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["basic", "map_cnn", "lane_cnn"])
+@pytest.mark.parametrize("mode", ["basic", "map_cnn", "lane_cnn", "basic-140"])
 def test_masked_autoregressive_decode_equals_the_step_by_step_decode(mode):
     """With dropout the tokens fed back depend on the masks.  At the shipped geometry the inference decoder's launch-per-phase
     kernels read the step's keep bytes (mmt_decoder_forward_dropout); everywhere else the engine decodes step by step on the
@@ -291,9 +291,11 @@ def test_masked_autoregressive_decode_equals_the_step_by_step_decode(mode):
     from multimodal_transformer_amd import ops, training
     from multimodal_transformer_amd.weights import apply_recipe
     dev = _gdev()
+    B = 24
+    if mode == "basic-140":          # 129..256 agents: still 4-agent clusters (more of them than CUs / 8 in every launch)
+        mode, B = "basic", 140
     hp, _, ph = hp_for(mode, False)
     hp["autoregressive"] = True
-    B = 24
     model, reg = _ours(hp, dev)
     apply_recipe(reg.model_dict, seed=0)
     t = {k: torch.from_numpy(v).to(dev) for k, v in batch_for(mode, False, B).items()}
