@@ -264,8 +264,12 @@ def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, grou
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "per_gpu_batch": B,
             "global_batch": B * world, "agents_per_s": B * world * steps / elapsed,
             "allreduce_ms": tr.allreduce_ms(), "allreduce_bytes": 4 * n_par if world > 1 else 0,
-            "parallelism": f"dp{world}, one flat fp32 all-reduce of {n_par} gradients per step (RCCL), parameters broadcast from "
-                           f"rank 0 at start" if world > 1 else "single GPU",
+            "allreduce_form": ("two buckets: the decoder-side gradients reduced asynchronously beside the history encoder's backward "
+                               "graph, the rest behind it; allreduce_ms = what the all-reduce adds between backward and optimizer "
+                               "(HIP events: first bucket issued -> last bucket reduced, minus that backward graph)")
+                              if tr.overlap else ("one bucket behind the backward" if world > 1 else None),
+            "parallelism": f"dp{world}, flat fp32 gradient of {n_par} elements all-reduced per step (RCCL) in two buckets, parameters "
+                           f"broadcast from rank 0 at start" if world > 1 else "single GPU",
             "dropout": ({"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
                          "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
                          "decode": ("mmt_decoder_forward_dropout: launch-per-phase 4-agent-cluster kernels reading the step's keep masks"

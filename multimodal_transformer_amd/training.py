@@ -512,11 +512,23 @@ class TrainEngine:
         self.named_params = named
         total = 0
         offs = []
-        for _, p in named:
+        enc_key, late_keys = nt + "/node_history_encoder.", (nt + "/lane_encoder.", nt + "/fusion/lane_hist.")
+        enc_end, late_start = 0, None
+        for name, p in named:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise MmtError("parameters must be contiguous fp32")
+            if late_start is None and name.startswith(late_keys):
+                late_start = total
             offs.append(total)
             total += (p.numel() + 63) & ~63
+            if name.startswith(enc_key):
+                enc_end = total
+        # backward() finishes the gradients in two stretches: decoder / head / map encoder / fusion first (the reverse-time sweep
+        # and the deferred weight-gradient GEMMs), then the history encoder (and the lane encoder / fusion/lane_hist, whose
+        # gradients come out of the memory's).  ``early_range`` can be all-reduced while the second stretch still runs.
+        late_start = total if late_start is None else late_start
+        self.early_range = (enc_end, late_start)
+        self.late_ranges = [r for r in ((0, enc_end), (late_start, total + 64)) if r[1] > r[0]]      # (+ the guard slot, below)
         # [0] is the gradient bucket (what the all-reduce and the optimizer see); [1..SPLITK-1] receive the other K-slices of
         # the split weight-gradient GEMMs at the same offsets and are summed into [0] at the end of backward()
         self.SPLITK = 4
@@ -847,11 +859,14 @@ class TrainEngine:
         if gb is not None:
             K.colsum(dY, gb)
 
-    def _sum_split_parts(self):
+    def _sum_split_parts(self, lo=0, hi=None):
         if getattr(self, "_split_used", False):
             t = self.grad_total
+            hi = t if hi is None else hi
+            if hi <= lo:
+                return
             for z in range(1, self.SPLITK):
-                K.add_inplace(self.flat_grad, self.flat_all[z * t:(z + 1) * t])
+                K.add_inplace(self.flat_grad[lo:hi], self.flat_all[z * t + lo:z * t + hi])
 
     def _ln_grad(self, dy, xhat, ln):
         if dy.shape[0] >= 512:
@@ -958,6 +973,11 @@ class TrainEngine:
 
     def backward(self):
         """Reverse-time sweep.  ``forward`` must have run; ``S.G[1:]`` holds dL/dpos from the loss kernel."""
+        self.backward_early()
+        self.backward_late()
+
+    def backward_early(self):
+        """The sweep and every gradient of ``early_range`` (decoder, head, map encoder, fusion/hist_map)."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
         enc, dec = self.enc, self.dec
         layers = dec.transformer_decoder.layers
@@ -1011,6 +1031,13 @@ class TrainEngine:
             self.cnn_tape.backward(self, gm)
         else:
             self.head_tape.wgrads(self, f2(S.ho), f2(S.G[1:]))
+        self._sum_split_parts(*self.early_range)
+
+    def backward_late(self):
+        """The history encoder's (and the lane branch's) gradients: ``late_ranges``, and the guard slot."""
+        S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
+        enc, dec = self.enc, self.dec
+        layers = dec.transformer_decoder.layers
         # ---- encoder: d memory = sum over decoder layers of d(memory K/V) W_kv
         gmem = S.gmemf if self.lane_mode else S.geh[self.Le]
         for l, lay in enumerate(layers):
@@ -1047,7 +1074,8 @@ class TrainEngine:
             self._wgrad(S.geo1m[l], S.eatt[l], sa.out_proj.weight, sa.out_proj.bias)
             self._wgrad(S.geqkv[l], S.eh[l], sa.in_proj_weight, sa.in_proj_bias)
         self._wgrad(S.geh[0], S.x0, enc.input_fc.weight, enc.input_fc.bias)
-        self._sum_split_parts()
+        for lo, hi in self.late_ranges:
+            self._sum_split_parts(lo, min(hi, self.grad_total))
         self.guard.copy_(self.loss)
 
     # ------------------------------------------------------------------ convenience
@@ -1108,12 +1136,16 @@ class Trainer:
     """Fused training step: forward + backward (one HIP graph), gradient all-reduce over RCCL when
     ``torch.distributed`` is initialised, clip-by-value + AdamW + ExponentialLR (second graph).
 
+    With more than one rank the backward is captured in two graphs and the all-reduce in two buckets: the decoder-side gradients
+    (``engine.early_range``, ~60 % of the bytes) are reduced asynchronously while the history encoder's backward still runs, the
+    rest behind it (``overlap=False``: one bucket after the whole backward, as in round 1).
+
     Optimizer semantics are train.py:218-256: AdamW(lr=hp.learning_rate, betas .9/.999, eps 1e-8, weight decay
     0.01), second parameter group 'map_encoder' at lr 8e-4, ``clip_grad_value_(hp.grad_clip)`` on the averaged
     gradient, ExponentialLR(hp.learning_decay_rate) stepped once per batch."""
 
     def __init__(self, model, B, T, ph, use_graph=True, process_group=None, distributed=True, always_reduce=False,
-                 dropout=None, seed=0):
+                 dropout=None, seed=0, overlap=True):
         """``dropout``: None = as the modules say (training mode and p > 0, like torch), False = the dropout-free graph.
         ``seed``: of the dropout masks; data-parallel ranks must pass different seeds (or masks repeat across shards)."""
         import torch.distributed as dist
@@ -1143,7 +1175,9 @@ class Trainer:
             entries.append((p.data, self.engine.g(p), m, v, scale))
         self.table, self.ntensors = K.adamw_table(entries, dev)
         self.use_graph = use_graph
-        self._g_fb = self._g_opt = None
+        self._g_fb = self._g_late = self._g_opt = None
+        self.reduces = self.world > 1 or self.always_reduce
+        self.overlap = bool(overlap) and self.reduces            # two backward graphs, two buckets
         self.steps_done = 0
         self.skipped = torch.zeros(1, dtype=torch.float32).to(dev)     # optimizer steps skipped because the loss was not finite
         self._skipped_seen = 0
@@ -1171,15 +1205,28 @@ class Trainer:
             raise RuntimeError("Trainer: parameters differ across data-parallel ranks after the broadcast")
 
     def allreduce_ms(self):
-        """Mean duration of the gradient all-reduce over the steps taken with ``time_allreduce`` set (None: never ran)."""
+        """Mean time per step that the gradient all-reduce adds between the backward and the optimizer, over the steps taken with
+        ``time_allreduce`` set (None: never ran).  With ``overlap`` this is what is NOT hidden behind the encoder's backward:
+        (first bucket issued -> last bucket reduced) minus the duration of that backward graph."""
         if not self._ar_events:
             return None
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self._ar_events) / len(self._ar_events)
+        tot = 0.0
+        for ev in self._ar_events:
+            tot += ev[0].elapsed_time(ev[1])
+            if len(ev) == 4:
+                tot -= ev[2].elapsed_time(ev[3])
+        return max(tot, 0.0) / len(self._ar_events)
 
     def _fwd_bwd(self):
         self.engine.forward()
-        self.engine.backward()
+        if self.overlap:
+            self.engine.backward_early()
+        else:
+            self.engine.backward()
+
+    def _bwd_late(self):
+        self.engine.backward_late()
 
     def _opt(self):
         K.adamw_step(self.table, self.ntensors, self.state, self.betas[0], self.betas[1], self.eps, self.wd, self.clip,
@@ -1200,7 +1247,7 @@ class Trainer:
                 why = str(e)
             warnings.warn(f"Trainer: {n - self._skipped_seen} optimizer step(s) skipped, weights untouched: {why}", RuntimeWarning)
             if self.use_graph:
-                self._g_fb = self._g_opt = None      # re-capture: the decoder form baked into the graph may be the one that failed
+                self._g_fb = self._g_late = self._g_opt = None      # re-capture: the decoder form baked into the graph may be the one that failed
         self._skipped_seen = n
         return n
 
@@ -1210,11 +1257,17 @@ class Trainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._fwd_bwd()
+            if self.overlap:
+                self._bwd_late()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fb):
             self._fwd_bwd()
+        if self.overlap:
+            self._g_late = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_late):
+                self._bwd_late()
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt):
             self._opt()
@@ -1229,7 +1282,31 @@ class Trainer:
             self._g_fb.replay()
         else:
             self._fwd_bwd()
-        if self.world > 1 or self.always_reduce:
+        if self.overlap:
+            import torch.distributed as dist
+            eng = self.engine
+            timed = self.time_allreduce and eng.flat_grad.is_cuda
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+            lo, hi = eng.early_range
+            if timed:
+                ev[0].record()
+            work = dist.all_reduce(eng.flat_grad[lo:hi], group=self.pg, async_op=True) if hi > lo else None
+            if timed:
+                ev[2].record()
+            if self.use_graph:
+                self._g_late.replay()                 # the encoder's backward, beside the first bucket's all-reduce
+            else:
+                self._bwd_late()
+            if timed:
+                ev[3].record()
+            if work is not None:
+                work.wait()                           # (orders the current stream behind the collective; the host does not block)
+            for lo, hi in eng.late_ranges:
+                dist.all_reduce(eng.flat_grad[lo:hi], group=self.pg)
+            if timed:
+                ev[1].record()
+                self._ar_events.append(tuple(ev))
+        elif self.reduces:
             import torch.distributed as dist
             if self.time_allreduce and self.engine.flat_grad.is_cuda:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

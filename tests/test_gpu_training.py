@@ -693,27 +693,32 @@ def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
     from multimodal_transformer_amd.weights import apply_recipe
     dev = _dev()
 
-    def run(reduce):
+    def run(reduce, overlap=True):
         hp = make_hyperparams("basic", history=8, horizon=12)
         model, reg = _model(hp, dev)
         apply_recipe(reg.model_dict, seed=2)
-        tr = training.Trainer(model, 128, 9, 12, use_graph=True, always_reduce=reduce)
-        assert tr.always_reduce == reduce
+        tr = training.Trainer(model, 128, 9, 12, use_graph=True, always_reduce=reduce, overlap=overlap)
+        assert tr.always_reduce == reduce and tr.overlap == (reduce and overlap)
+        tr.time_allreduce = reduce
         losses = []
         for it in range(4):
             b = make_batch(128, 8, 12, seed=20 + it)
             losses.append(float(tr.step(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev))))
+        if reduce:
+            assert tr.allreduce_ms() is not None and tr.allreduce_ms() >= 0.0
         return losses, torch.cat([p.detach().reshape(-1) for p in reg.parameters()]).clone()
 
     plain = run(False)
     dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
     try:
         dist.barrier()
-        reduced = run(True)
+        reduced = run(True)                    # two backward graphs, the decoder-side bucket reduced beside the second one
+        one_bucket = run(True, overlap=False)  # round 1's form: one bucket behind the whole backward
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
     assert plain[0] == reduced[0] and torch.equal(plain[1], reduced[1])
+    assert plain[0] == one_bucket[0] and torch.equal(plain[1], one_bucket[1])
 
 
 def test_a_step_whose_decode_gave_up_leaves_the_weights_alone():

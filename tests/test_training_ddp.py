@@ -43,7 +43,8 @@ def _worker(rank, world, port, out_dir):
     shard = slice(rank * B // world, (rank + 1) * B // world)
     model, reg = build()
     tr = training.Trainer(model, B // world, 5, 3, use_graph=False, dropout=False)
-    assert tr.world == world
+    assert tr.world == world and tr.overlap            # two buckets: the decoder side reduced beside the encoder's backward
+    assert tr.engine.early_range[1] > tr.engine.early_range[0]
     for b in batches:
         tr.step(torch.from_numpy(b["x_st"][shard]), torch.from_numpy(b["y_st"][shard]))
     ref_model, ref_reg = build()

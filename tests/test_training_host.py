@@ -226,3 +226,39 @@ def test_teacher_forced_step_matches_reference_non_at_dec(monkeypatch):
             ok, e = check_post_step(p.detach().numpy(), z["post::" + key], z["grad::" + key] if "grad::" + key in z.files
                                     else None, hp["learning_rate"])
             assert ok, (key, e)
+
+
+@pytest.mark.parametrize("mode", ["basic", "map_cnn", "lane_cnn"])
+def test_gradient_buckets_partition_the_flat_buffer_by_completion_time(monkeypatch, mode):
+    """The overlapped all-reduce (Trainer, world > 1) sends ``early_range`` while ``backward_late`` still runs: the two sets of
+    ranges must tile the flat buffer, every history-encoder / lane-branch gradient must lie in a late range, and
+    backward_early() + backward_late() must leave exactly what backward() leaves."""
+    from multimodal_transformer_amd import training
+    fake_kernels.install(monkeypatch)
+    hp, B, ph = hp_for(mode, True)
+    hp["autoregressive"] = True
+    model, reg = _model(hp)
+    z, _ = load_golden("tiny_" + mode)
+    set_weights(reg.model_dict, True, z)
+    batch = batch_for(mode, True)
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    eng = training.TrainEngine(model, t["x_st"].shape[0], t["x_st"].shape[1], ph)
+    lo, hi = eng.early_range
+    spans = sorted([(lo, hi)] + list(eng.late_ranges))
+    assert spans[0][0] == 0 and spans[-1][1] == eng.grad_total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    base = eng.flat_grad.data_ptr()
+    for name, g in eng.grad_by_name.items():
+        off = (g.data_ptr() - base) // 4
+        late = any(a <= off < b for a, b in eng.late_ranges)
+        assert late == (("node_history_encoder" in name) or ("lane" in name)), name
+    eng.set_batch(t["x_st"], t["y_st"], t.get("map"), t.get("lanes"))
+    eng.forward()
+    eng.backward()
+    whole = eng.flat_grad.clone()
+    eng.forward()
+    eng.backward_early()
+    early = eng.flat_grad[lo:hi].clone()
+    eng.backward_late()
+    assert torch.equal(early, eng.flat_grad[lo:hi])          # the late stretch does not touch the early bucket
+    assert torch.equal(whole, eng.flat_grad)
