@@ -206,6 +206,14 @@ typedef struct {
   int32_t pad_;
 } mmt_adamw_tensor;
 
+/* one job of mmt_ln_grad_group: the arguments of mmt_ln_param_grads */
+typedef struct {
+  const float *dy, *xhat;
+  float *gw, *gb;
+  int64_t ld, part_stride;
+  int32_t M, N, splitk, pad_;
+} mmt_ln_grad_job;
+
 const char *mmt_last_error(void);
 int mmt_version(void);
 
@@ -377,6 +385,17 @@ int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int N, long ld
                        long part_stride, void *stream);
 int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,
                float *out, int accumulate, void *stream);
+/* Group launches (no reference counterpart: torch's autograd issues one kernel per parameter gradient, train.py:244-246): the
+ * deferred weight gradients of a step are ~70 independent split-K GEMMs (each an mmt_gemm call with splitk >= 1 / asum) and ~30
+ * LayerNorm parameter reductions over the same ph*B rows, each far too small to fill 256 CUs; ONE launch runs all tiles of all
+ * jobs, tile for tile the arithmetic of the single-job launch (bit-identical results).  *_plan validates the jobs as the
+ * single-job entry point would and writes the launch table [njobs jobs][nblocks {job, bx, by, bz}] into host memory
+ * (table_host == NULL: sizes only); the caller copies it to 16-byte aligned device memory once and launches it any number of
+ * times (graph-capturable; the jobs' pointers are baked into the table). */
+int mmt_gemm_group_plan(const mmt_gemm_args *jobs, int njobs, void *table_host, size_t capacity, size_t *bytes, int *nblocks);
+int mmt_gemm_group(const void *table_dev, int njobs, int nblocks, void *stream);
+int mmt_ln_grad_group_plan(const mmt_ln_grad_job *jobs, int njobs, void *table_host, size_t capacity, size_t *bytes, int *nblocks);
+int mmt_ln_grad_group(const void *table_dev, int njobs, int nblocks, void *stream);
 /* y = [relu](LayerNorm(x + res)) with eps 1e-5; stashes xhat (M,N), rstd (M)   (nn.LayerNorm; MLP.py:13-16) */
 int mmt_layernorm_fwd(const float *x, const float *res, int M, int N, const float *g, const float *b, int relu,
                       float *y, float *xhat, float *rstd, void *stream);

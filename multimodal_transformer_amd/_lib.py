@@ -112,6 +112,11 @@ class PackJob(C.Structure):
                [(n, C.c_int32) for n in ("kind", "n", "k", "ldw", "col0", "nparts", "part_rows", "slice_rows", "nslices", "pad_")]
 
 
+class LnGradJob(C.Structure):
+    _fields_ = [("dy", fptr), ("xhat", fptr), ("gw", fptr), ("gb", fptr), ("ld", C.c_int64), ("part_stride", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("splitk", C.c_int32), ("pad_", C.c_int32)]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [("param", fptr), ("grad", fptr), ("exp_avg", fptr), ("exp_avg_sq", fptr), ("numel", C.c_int64),
                 ("lr_scale", C.c_float), ("pad_", C.c_int32)]
@@ -161,6 +166,11 @@ SIGNATURES = {
     "mmt_col2im": (C.c_int, [fptr, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fptr, C.c_float, fptr,
                              C.c_long, C.c_void_p]),
     "mmt_ln_param_grads": (C.c_int, [fptr, fptr, C.c_int, C.c_int, C.c_long, fptr, fptr, C.c_int, C.c_long, C.c_void_p]),
+    "mmt_gemm_group_plan": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "mmt_gemm_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mmt_ln_grad_group_plan": (C.c_int, [C.POINTER(LnGradJob), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_int)]),
+    "mmt_ln_grad_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "mmt_colsum": (C.c_int, [fptr, fptr, fptr, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, fptr, C.c_int, C.c_void_p]),
     "mmt_layernorm_fwd": (C.c_int, [fptr, fptr, C.c_int, C.c_int, fptr, fptr, C.c_int, fptr, fptr, fptr, C.c_void_p]),
     "mmt_layernorm_bwd": (C.c_int, [fptr, fptr, fptr, fptr, fptr, C.c_int, C.c_int, fptr, C.c_int, fptr, fptr, C.c_float, fptr,

@@ -220,6 +220,62 @@ def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
                "mmt_ln_param_grads")
 
 
+# ---- group launches: many independent jobs of one kind in ONE launch ------------------------------------------------
+_GROUP_TABLES = {}       # host table bytes -> (device copy, njobs, nblocks); the jobs' pointers are part of the key
+
+
+def _group_launch(kind, jobs, plan, run, what):
+    """jobs: ctypes array of job structs.  The launch table is planned on the host and uploaded once per distinct job list
+    (a later call with the same pointers and shapes -- every replay of a captured step -- finds it by its bytes)."""
+    key = (kind, bytes(jobs))
+    hit = _GROUP_TABLES.get(key)
+    lib = _lib.load()
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise MmtError(f"{what}: first use of this job list inside a graph capture; run the step once eagerly first")
+        nbytes, nblocks = C.c_size_t(0), C.c_int(0)
+        _lib.check(plan(jobs, len(jobs), None, 0, C.byref(nbytes), C.byref(nblocks)), what + "_plan")
+        host = (C.c_uint8 * nbytes.value)()
+        _lib.check(plan(jobs, len(jobs), host, nbytes.value, C.byref(nbytes), C.byref(nblocks)), what + "_plan")
+        table = torch.frombuffer(host, dtype=torch.uint8).clone().to(torch.cuda.current_device())
+        if len(_GROUP_TABLES) >= 64:       # engines come and go in a test session: keep the cache bounded
+            _GROUP_TABLES.pop(next(iter(_GROUP_TABLES)))
+        hit = _GROUP_TABLES[key] = (table, len(jobs), nblocks.value)
+    table, njobs, nblocks = hit
+    _lib.check(run(C.c_void_p(table.data_ptr()), njobs, nblocks, _stream()), what)
+
+
+def gemm_group(calls):
+    """``calls``: list of keyword dicts, each the arguments of a split-K / asum ``gemm`` (the deferred weight gradients of a
+    step).  One launch runs the tiles of all of them; results are those of the separate calls, bit for bit."""
+    if not calls:
+        return
+    lib = _lib.load()
+    jobs = (_lib.GemmArgs * len(calls))(*[_gemm_args(**kw) for kw in calls])
+    _group_launch("gemm", jobs, lib.mmt_gemm_group_plan, lib.mmt_gemm_group, "mmt_gemm_group")
+
+
+def ln_param_grads_group(calls):
+    """``calls``: list of keyword dicts, each the arguments of ``ln_param_grads``; one launch."""
+    if not calls:
+        return
+    lib = _lib.load()
+    jobs = (_lib.LnGradJob * len(calls))()
+    for J, kw in zip(jobs, calls):
+        dy, xhat, gw, gb = kw["dy"], kw["xhat"], kw["gw"], kw["gb"]
+        ld = _rows(dy, "dy")
+        M, N = dy.shape
+        if tuple(xhat.shape) != (M, N) or _rows(xhat, "xhat") != ld:
+            raise MmtError("ln_param_grads: dy and xhat must have the same shape and row stride")
+        for t, n in ((gw, "gw"), (gb, "gb")):
+            _dev(t, n)
+            if t.numel() != N or not t.is_contiguous():
+                raise MmtError(f"ln_param_grads: {n} must be a contiguous vector of N elements")
+        J.dy, J.xhat, J.gw, J.gb = dy.data_ptr(), xhat.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        J.ld, J.part_stride, J.M, J.N, J.splitk = ld, int(kw.get("part_stride", 0)), M, N, int(kw.get("splitk", 1))
+    _group_launch("ln", jobs, lib.mmt_ln_grad_group_plan, lib.mmt_ln_grad_group, "mmt_ln_grad_group")
+
+
 def _contig2(t, name, shape=None):
     _dev(t, name)
     if not t.is_contiguous() or (shape is not None and tuple(t.shape) != tuple(shape)):

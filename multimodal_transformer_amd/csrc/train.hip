@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <stdint.h>
 #include "../../include/mmt_amd.h"
 
@@ -60,29 +61,29 @@ __device__ __forceinline__ float gemm_epi(const mmt_gemm_args &g, float v, int m
 }
 __device__ __forceinline__ float keep_of(uint32_t bytes, int e, float scale) { return ((bytes >> (8 * e)) & 0xffu) ? scale : 0.f; }
 
-template <int BT, bool AK, bool BK, bool SPLIT = false>
-__global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
+// (bx, by, bz) = the tile this workgroup owns: blockIdx of a single-job launch, or what the block map of a group launch says
+template <int BT, bool AK, bool BK, bool SPLIT>
+__device__ __forceinline__ void gemm_panel_body(mmt_gemm_args g, const int bx, const int by, const int bz, float *smem) {
   constexpr int KC = 64, LDK = KC + 4, LDR = BT + 4;
   constexpr int ASZ = AK ? BT * LDK : KC * LDR, BSZ = BK ? BT * LDK : KC * LDR;
   constexpr int NI = BT / 16;      // 16-byte loads per thread per operand per panel
   constexpr int WT = BT / 32;      // 16x16 MFMA tiles per wave per dimension
   constexpr int R4 = BT / 4;
-  extern __shared__ __align__(16) float smem[];
   float *As = smem, *Bs = smem + 2 * ASZ;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+  const int m0 = by * BT, n0 = bx * BT;
   const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
   const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
   f32x4 ar[NI], br[NI];
   int kbeg = 0, kend = g.K;
   if constexpr (SPLIT) {
     const int per = (((g.K + g.splitk - 1) / g.splitk) + KC - 1) / KC * KC;
-    kbeg = min(g.K, (int)blockIdx.z * per);
+    kbeg = min(g.K, bz * per);
     kend = min(g.K, kbeg + per);
-    g.C += (size_t)blockIdx.z * g.part_stride;
+    g.C += (size_t)bz * g.part_stride;
   }
   f32x4 rsum = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_sum = SPLIT && g.asum && blockIdx.x == 0;
+  const bool do_sum = SPLIT && g.asum && bx == 0;
   auto gload = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
@@ -180,10 +181,31 @@ __global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
       if (tid < BT && m0 + tid < g.M) {
         float t = 0.f;
         for (int r = 0; r < 256 / R4; ++r) t += ps[r * BT + tid];
-        g.asum[(size_t)blockIdx.z * g.part_stride + m0 + tid] = t;
+        g.asum[(size_t)bz * g.part_stride + m0 + tid] = t;
       }
     }
   }
+}
+
+template <int BT, bool AK, bool BK, bool SPLIT = false>
+__global__ __launch_bounds__(256) void mmt_gemm_panel_kernel(mmt_gemm_args g) {
+  extern __shared__ __align__(16) float smem[];
+  gemm_panel_body<BT, AK, BK, SPLIT>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Group launch: workgroup i works on tile map[i] = (job, bx, by, bz) of the split-K weight-gradient GEMM jobs[job] (same body, same
+// split, same sums as that job's own launch would give).  The deferred weight gradients of a training step are ~70 independent
+// GEMMs of 64..1536 tiles each: one launch of all their tiles fills the chip where 70 launches each leave most of it idle.
+struct GroupBlock {
+  int32_t job, bx, by, bz;
+};
+template <int BT>
+__global__ __launch_bounds__(256) void mmt_gemm_group_kernel(const mmt_gemm_args *__restrict__ jobs, const GroupBlock *__restrict__ map) {
+  extern __shared__ __align__(16) float smem[];
+  const GroupBlock m = map[blockIdx.x];
+  const int j = __builtin_amdgcn_readfirstlane(m.job);
+  gemm_panel_body<BT, false, false, true>(jobs[j], __builtin_amdgcn_readfirstlane(m.bx), __builtin_amdgcn_readfirstlane(m.by),
+                                          __builtin_amdgcn_readfirstlane(m.bz), smem);
 }
 
 template <int BT, bool AK, bool BK>
@@ -512,13 +534,14 @@ __global__ __launch_bounds__(256) void mmt_gemm_kernel(mmt_gemm_args g) {
 
 // LayerNorm parameter gradients in one pass: gw[n] = sum_m dy[m][n] * xhat[m][n], gb[n] = sum_m dy[m][n].  The rows are
 // dealt over gridDim.y slices (slice z -> out + z*part_stride, summed by the caller like the split weight gradients).
-__global__ __launch_bounds__(1024) void mmt_ln_param_grads_kernel(const float *__restrict__ dy, const float *__restrict__ xhat, int M,
-                                                                  int N, long ld, float *__restrict__ gw, float *__restrict__ gb,
-                                                                  long part_stride) {
+// (bx, bz of nz) = column block and row slice: blockIdx / gridDim.y of a single-job launch, or a group launch's block map
+__device__ __forceinline__ void ln_param_grads_body(const float *__restrict__ dy, const float *__restrict__ xhat, int M, int N, long ld,
+                                                    float *__restrict__ gw, float *__restrict__ gb, long part_stride, const int bx,
+                                                    const int bz, const int nz) {
   __shared__ float pw[64][17], pb[64][17];
   __shared__ float qw[4][16], qb[4][16];
-  const int cl = threadIdx.x & 15, c = blockIdx.x * 16 + cl, rl = threadIdx.x >> 4;
-  const int per = (M + gridDim.y - 1) / gridDim.y, mb = blockIdx.y * per, me = min(M, mb + per);
+  const int cl = threadIdx.x & 15, c = bx * 16 + cl, rl = threadIdx.x >> 4;
+  const int per = (M + nz - 1) / nz, mb = bz * per, me = min(M, mb + per);
   float sw = 0.f, sb = 0.f;
   if (c < N) {
 #pragma unroll 4
@@ -542,9 +565,21 @@ __global__ __launch_bounds__(1024) void mmt_ln_param_grads_kernel(const float *_
   }
   __syncthreads();
   if (rl == 0 && c < N) {
-    gw[(size_t)blockIdx.y * part_stride + c] = (qw[0][cl] + qw[1][cl]) + (qw[2][cl] + qw[3][cl]);
-    gb[(size_t)blockIdx.y * part_stride + c] = (qb[0][cl] + qb[1][cl]) + (qb[2][cl] + qb[3][cl]);
+    gw[(size_t)bz * part_stride + c] = (qw[0][cl] + qw[1][cl]) + (qw[2][cl] + qw[3][cl]);
+    gb[(size_t)bz * part_stride + c] = (qb[0][cl] + qb[1][cl]) + (qb[2][cl] + qb[3][cl]);
   }
+}
+__global__ __launch_bounds__(1024) void mmt_ln_param_grads_kernel(const float *__restrict__ dy, const float *__restrict__ xhat, int M,
+                                                                  int N, long ld, float *__restrict__ gw, float *__restrict__ gb,
+                                                                  long part_stride) {
+  ln_param_grads_body(dy, xhat, M, N, ld, gw, gb, part_stride, blockIdx.x, blockIdx.y, gridDim.y);
+}
+// group launch (as mmt_gemm_group_kernel): workgroup i reduces block map[i] = (job, bx, -, bz) of jobs[job]
+__global__ __launch_bounds__(1024) void mmt_ln_grad_group_kernel(const mmt_ln_grad_job *__restrict__ jobs, const GroupBlock *__restrict__ map) {
+  const GroupBlock m = map[blockIdx.x];
+  const mmt_ln_grad_job J = jobs[__builtin_amdgcn_readfirstlane(m.job)];
+  ln_param_grads_body(J.dy, J.xhat, J.M, J.N, J.ld, J.gw, J.gb, J.part_stride, __builtin_amdgcn_readfirstlane(m.bx),
+                      __builtin_amdgcn_readfirstlane(m.bz), J.splitk);
 }
 
 // out[n] (+)= sum_m a[m][n] * (b ? b[m][n] : 1) [only where mask[m][n] > 0]; deterministic order.
@@ -1269,6 +1304,86 @@ extern "C" int mmt_ln_param_grads(const float *dy, const float *xhat, int M, int
   hipLaunchKernelGGL(mmt_ln_param_grads_kernel, dim3((N + 15) / 16, splitk), dim3(1024), 0, (hipStream_t)stream, dy, xhat, M, N, ld,
                      gw, gb, part_stride);
   return launch_ok("mmt_ln_param_grads");
+}
+
+// ---- group launches: the table is [njobs job structs][nblocks GroupBlock], built on the host by *_plan (which validates every
+// job as the single-job entry point would), copied to device memory by the caller once and launched any number of times
+static bool split_job_ok(const mmt_gemm_args *g) {
+  if (!g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0 || g->K <= 0) return false;
+  const bool ar = g->sam == 1 && g->sak % 4 == 0 && g->M % 4 == 0, br = g->sbn == 1 && g->sbk % 4 == 0 && g->N % 4 == 0;
+  const bool aligned = (((uintptr_t)g->A | (uintptr_t)g->B) & 15) == 0 && g->K % 4 == 0;
+  const double amax = (double)g->M + (double)g->K * (double)g->sak, bmax = (double)g->N + (double)g->K * (double)g->sbk;
+  return aligned && ar && br && amax < 5e8 && bmax < 5e8 && !g->bias && !g->addend && !g->mask && !g->relu && !g->accumulate &&
+         !g->ln_xhat && !g->drop && g->splitk <= 16 && (g->splitk <= 1 || g->part_stride > 0);
+}
+template <class Job, class Blocks>
+static int group_plan(const char *who, const Job *jobs, int njobs, void *table_host, size_t capacity, size_t *bytes, int *nblocks,
+                      Blocks blocks_of) {
+  if (!jobs || njobs <= 0 || !bytes || !nblocks) return mmt_set_error(MMT_EINVAL, "%s: null pointer / no jobs", who);
+  long total = 0;
+  for (int j = 0; j < njobs; ++j) {
+    int nx, ny, nz;
+    if (!blocks_of(jobs[j], nx, ny, nz)) return mmt_set_error(MMT_EINVAL, "%s: job %d is not one the group kernel takes", who, j);
+    total += (long)nx * ny * nz;
+  }
+  if (total > (1l << 30)) return mmt_set_error(MMT_EINVAL, "%s: too many workgroups", who);
+  *nblocks = (int)total;
+  *bytes = (size_t)njobs * sizeof(Job) + (size_t)total * sizeof(GroupBlock);
+  if (!table_host) return MMT_OK;
+  if (capacity < *bytes) return mmt_set_error(MMT_EINVAL, "%s: table needs %zu bytes, %zu given", who, *bytes, capacity);
+  memcpy(table_host, jobs, (size_t)njobs * sizeof(Job));
+  GroupBlock *map = reinterpret_cast<GroupBlock *>(static_cast<char *>(table_host) + (size_t)njobs * sizeof(Job));
+  for (int j = 0; j < njobs; ++j) {
+    int nx, ny, nz;
+    blocks_of(jobs[j], nx, ny, nz);
+    for (int z = 0; z < nz; ++z)
+      for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) *map++ = GroupBlock{j, x, y, z};
+  }
+  return MMT_OK;
+}
+constexpr int GROUP_BT = 32;
+extern "C" int mmt_gemm_group_plan(const mmt_gemm_args *jobs, int njobs, void *table_host, size_t capacity, size_t *bytes, int *nblocks) {
+  return group_plan("mmt_gemm_group_plan", jobs, njobs, table_host, capacity, bytes, nblocks,
+                    [](const mmt_gemm_args &g, int &nx, int &ny, int &nz) {
+                      if (!split_job_ok(&g)) return false;
+                      nx = (g.N + GROUP_BT - 1) / GROUP_BT, ny = (g.M + GROUP_BT - 1) / GROUP_BT, nz = std::max(g.splitk, 1);
+                      return true;
+                    });
+}
+extern "C" int mmt_gemm_group(const void *table_dev, int njobs, int nblocks, void *stream) {
+  if (!table_dev || njobs <= 0 || nblocks <= 0 || ((uintptr_t)table_dev & 15))
+    return mmt_set_error(MMT_EINVAL, "mmt_gemm_group: null / misaligned table or nothing to do");
+  constexpr int KC = 64, LDR = GROUP_BT + 4;
+  constexpr size_t lds = 2 * (KC * LDR + KC * LDR) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)mmt_gemm_group_kernel<GROUP_BT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const mmt_gemm_args *jobs = static_cast<const mmt_gemm_args *>(table_dev);
+  hipLaunchKernelGGL((mmt_gemm_group_kernel<GROUP_BT>), dim3(nblocks), dim3(256), lds, (hipStream_t)stream, jobs,
+                     reinterpret_cast<const GroupBlock *>(jobs + njobs));
+  return launch_ok("mmt_gemm_group");
+}
+extern "C" int mmt_ln_grad_group_plan(const mmt_ln_grad_job *jobs, int njobs, void *table_host, size_t capacity, size_t *bytes,
+                                      int *nblocks) {
+  return group_plan("mmt_ln_grad_group_plan", jobs, njobs, table_host, capacity, bytes, nblocks,
+                    [](const mmt_ln_grad_job &J, int &nx, int &ny, int &nz) {
+                      if (!J.dy || !J.xhat || !J.gw || !J.gb || J.M <= 0 || J.N <= 0 || J.splitk < 1 || J.splitk > 64 ||
+                          (J.splitk > 1 && J.part_stride <= 0))
+                        return false;
+                      nx = (J.N + 15) / 16, ny = 1, nz = J.splitk;
+                      return true;
+                    });
+}
+extern "C" int mmt_ln_grad_group(const void *table_dev, int njobs, int nblocks, void *stream) {
+  if (!table_dev || njobs <= 0 || nblocks <= 0 || ((uintptr_t)table_dev & 15))
+    return mmt_set_error(MMT_EINVAL, "mmt_ln_grad_group: null / misaligned table or nothing to do");
+  const mmt_ln_grad_job *jobs = static_cast<const mmt_ln_grad_job *>(table_dev);
+  hipLaunchKernelGGL(mmt_ln_grad_group_kernel, dim3(nblocks), dim3(1024), 0, (hipStream_t)stream, jobs,
+                     reinterpret_cast<const GroupBlock *>(jobs + njobs));
+  return launch_ok("mmt_ln_grad_group");
 }
 
 extern "C" int mmt_colsum(const float *a, const float *b, const float *mask, int M, int N, long lda, long ldb, long ldm,

@@ -852,12 +852,33 @@ class TrainEngine:
         N = X.shape[1]
         if R >= 512 and M % 4 == 0 and N % 4 == 0 and M >= 32 and N >= 32 and dY.stride(1) == 1 and X.stride(1) == 1:
             # one pass: K range split over SPLITK workgroup slices, bias gradient from the same operand tiles
-            K.gemm(dY.t(), X, gw, splitk=self.SPLITK, part_stride=self.grad_total, asum=gb)
+            kw = dict(A=dY.t(), B=X, Cm=gw, splitk=self.SPLITK, part_stride=self.grad_total, asum=gb)
+            if self._deferred is not None:
+                self._deferred[0].append(kw)
+            else:
+                K.gemm(**kw)
             self._split_used = True
             return
         K.gemm(dY.t(), X, gw)
         if gb is not None:
             K.colsum(dY, gb)
+
+    _deferred = None
+
+    def _defer_wgrads(self):
+        """From here to ``_flush_wgrads`` the split-K weight-gradient GEMMs and LayerNorm parameter reductions are collected
+        instead of launched: they are independent of each other (each reads stashes that nothing rewrites before the flush and
+        writes its own slice of the gradient buffer) and go out as ONE launch per kind -- ~70 GEMMs of 64..384 tiles each fill
+        the chip together where each alone leaves most of it idle (``group_wgrads = False``: one launch each, same bits)."""
+        if getattr(self, "group_wgrads", True):
+            self._deferred = ([], [])
+
+    def _flush_wgrads(self):
+        if self._deferred is not None:
+            gemms, lns = self._deferred
+            self._deferred = None
+            K.gemm_group(gemms)
+            K.ln_param_grads_group(lns)
 
     def _sum_split_parts(self, lo=0, hi=None):
         if getattr(self, "_split_used", False):
@@ -870,7 +891,11 @@ class TrainEngine:
 
     def _ln_grad(self, dy, xhat, ln):
         if dy.shape[0] >= 512:
-            K.ln_param_grads(dy, xhat, self.g(ln.weight), self.g(ln.bias), splitk=self.SPLITK, part_stride=self.grad_total)
+            kw = dict(dy=dy, xhat=xhat, gw=self.g(ln.weight), gb=self.g(ln.bias), splitk=self.SPLITK, part_stride=self.grad_total)
+            if self._deferred is not None:
+                self._deferred[1].append(kw)
+            else:
+                K.ln_param_grads(**kw)
             self._split_used = True
         else:
             K.ln_param_grads(dy, xhat, self.g(ln.weight), self.g(ln.bias))
@@ -1001,6 +1026,7 @@ class TrainEngine:
         # ---- deferred decoder weight gradients: one GEMM per Linear over all ph*B rows
         R = ph * B
         f2 = lambda t: t.view(R, t.shape[-1])
+        self._defer_wgrads()
         self._wgrad(f2(S.gx[0]), f2(S.tok), dec.input_fc.weight, dec.input_fc.bias)
         memory = S.memf if self.lane_mode else S.eh[self.Le]          # what the cross-attention K/V were projected from
         for l, lay in enumerate(layers):
@@ -1020,6 +1046,7 @@ class TrainEngine:
         if self.map_mode:
             self.head_tape.wgrads(self, f2(S.u), f2(S.G[1:]))
             self.fuse_tape.wgrads(self, f2(S.hcat), f2(self.head_tape.gin))
+            self._flush_wgrads()          # (the map encoder's tapes re-use their gradient buffers: their GEMMs go out one by one)
             # d encoded_map = sum over the steps of the concatenation's last columns, then back through the CNN
             K.colsum(self.fuse_tape.gin.view(ph, B * self.fuse_tape.k_in), S.gmap)
             gm = S.gmap.view(B, self.fuse_tape.k_in)[:, self.n_out:]
@@ -1031,6 +1058,7 @@ class TrainEngine:
             self.cnn_tape.backward(self, gm)
         else:
             self.head_tape.wgrads(self, f2(S.ho), f2(S.G[1:]))
+            self._flush_wgrads()
         self._sum_split_parts(*self.early_range)
 
     def backward_late(self):
@@ -1040,6 +1068,7 @@ class TrainEngine:
         layers = dec.transformer_decoder.layers
         # ---- encoder: d memory = sum over decoder layers of d(memory K/V) W_kv
         gmem = S.gmemf if self.lane_mode else S.geh[self.Le]
+        self._defer_wgrads()              # (every buffer the collected jobs read is per layer and written once per step)
         for l, lay in enumerate(layers):
             K.gemm(S.gmkv[l], lay.multihead_attn.in_proj_weight[d:], gmem, accumulate=(l > 0))
         if self.lane_mode:
@@ -1074,6 +1103,7 @@ class TrainEngine:
             self._wgrad(S.geo1m[l], S.eatt[l], sa.out_proj.weight, sa.out_proj.bias)
             self._wgrad(S.geqkv[l], S.eh[l], sa.in_proj_weight, sa.in_proj_bias)
         self._wgrad(S.geh[0], S.x0, enc.input_fc.weight, enc.input_fc.bias)
+        self._flush_wgrads()
         for lo, hi in self.late_ranges:
             self._sum_split_parts(lo, min(hi, self.grad_total))
         self.guard.copy_(self.loss)

@@ -131,6 +131,16 @@ def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
     gb.copy_(dy.double().sum(0).to(gb.dtype))
 
 
+def gemm_group(calls):
+    for kw in calls:
+        gemm(**kw)
+
+
+def ln_param_grads_group(calls):
+    for kw in calls:
+        ln_param_grads(**kw)
+
+
 def layernorm_fwd(x, res, g, b, y, xhat, rstd, relu=False):
     v = x.double() + (res.double() if res is not None else 0.0)
     mu = v.mean(-1, keepdim=True)
@@ -289,7 +299,7 @@ def ar_decode(eng):
         S.pos[s + 1].copy_(S.pos[s] + S.delta[s])
 
 
-ALL = ("dropout_mask", "rng_advance", "dropout_apply", "im2col", "col2im", "gemm_attention_bwd_ok", "gemm_attention_bwd", "ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
+ALL = ("gemm_group", "ln_param_grads_group", "dropout_mask", "rng_advance", "dropout_apply", "im2col", "col2im", "gemm_attention_bwd_ok", "gemm_attention_bwd", "ln_param_grads", "softmax_axis", "cumsum_axis", "add_inplace", "gemm", "colsum", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd", "l2_loss_bwd",
        "history_prepare", "adamw_table", "adamw_step", "lr_step")
 
 

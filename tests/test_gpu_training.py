@@ -549,6 +549,33 @@ def test_full_width_gradients_agree_between_fused_and_separate_kernels(B):
     assert rel_err(out[0][1].cpu().numpy(), out[1][1].cpu().numpy()) <= 1e-5
 
 
+@pytest.mark.parametrize("mode,B", [("basic", 128), ("map_cnn", 64), ("lane_cnn", 200)])
+def test_grouped_weight_gradient_launch_is_bit_identical_to_one_launch_per_gradient(mode, B):
+    """The deferred weight-gradient GEMMs / LayerNorm parameter reductions as ONE launch per kind (mmt_gemm_group,
+    mmt_ln_grad_group) against one launch each: the same tiles, the same sums -- every gradient bit for bit."""
+    from multimodal_transformer_amd import training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _dev()
+    b = make_batch(B, 8, 12, seed=7, with_map=(mode == "map_cnn"), with_lanes=(mode == "lane_cnn"))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    out = []
+    for grouped in (True, False, True):
+        hp = make_hyperparams(mode, history=8, horizon=12)
+        model, reg = _model(hp, dev)
+        apply_recipe(reg.model_dict, seed=4)
+        eng = training.TrainEngine(model, B, 9, 12, dropout=False)
+        eng.group_wgrads = grouped
+        eng.set_batch(t["x_st"], t["y_st"], maps=t.get("map"), lanes=t.get("lanes"))
+        loss = float(eng.forward())
+        eng.backward()
+        out.append((loss, eng.flat_grad.clone()))
+    assert np.isfinite(out[0][0]) and float(out[0][1].abs().max()) > 0
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1], out[2][1])
+
+
 def test_autograd_entry_point_on_device():
     """The reference's loop body verbatim: zero_grad / train_loss / backward / clip / torch AdamW."""
     dev = _dev()

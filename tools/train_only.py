@@ -1,5 +1,5 @@
 """Profiling workload: N Basic training steps at batch B (rocprofv3 --kernel-trace target), eager (no graph) so that every
-kernel shows up by name.  python tools/train_only.py [B] [N] [dropout 0/1] [graph 0/1] [sweep ways]"""
+kernel shows up by name.  python tools/train_only.py [B] [N] [dropout 0/1] [graph 0/1] [sweep ways] [grouped weight gradients 0/1]"""
 import os
 import sys
 import time
@@ -23,6 +23,8 @@ x_st, y_st = torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to
 tr = Trainer(model, B, 9, 12, use_graph=graph, dropout=None if drop else False)
 if len(sys.argv) > 5:
     tr.engine.sweep_ways = int(sys.argv[5])
+if len(sys.argv) > 6:
+    tr.engine.group_wgrads = bool(int(sys.argv[6]))
 for _ in range(3):
     tr.step(x_st, y_st)
 torch.cuda.synchronize()
