@@ -59,6 +59,42 @@ __device__ __forceinline__ float gemm_epi(const mmt_gemm_args &g, float v, int m
   }
   return v;
 }
+// the same epilogue on operands requested at kernel entry (the row-block kernel: a load at the end of a 5 us kernel is a memory
+// round trip on the sweep's critical path); absent operands were "loaded" out of range and read as zero
+struct EpiPre {
+  float bias, add, mask;
+  uint32_t keep;
+};
+__device__ __forceinline__ EpiPre gemm_epi_load(const mmt_gemm_args &g, int m, int n, bool ok) {
+  EpiPre p;
+  p.bias = bl1(mk_rsrc(g.bias), (g.bias && ok) ? (unsigned)n * 4u : OOB);
+  p.add = bl1(mk_rsrc(g.addend), (g.addend && ok) ? (unsigned)(m * (int)g.ld_add + n) * 4u : OOB);
+  p.mask = bl1(mk_rsrc(g.mask), (g.mask && ok) ? (unsigned)(m * (int)g.ld_mask + n) * 4u : OOB);
+  p.keep = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(g.drop), (g.drop && ok) ? (unsigned)(m * (int)g.ld_drop + n) : OOB, 0, 0);
+  return p;
+}
+__device__ __forceinline__ float gemm_epi_pre(const mmt_gemm_args &g, float v, const EpiPre &p) {
+  if (g.bias) v += p.bias;
+  if (g.drop) {
+    const float keep = (p.keep & 0xffu) ? g.drop_scale : 0.f;
+    if (g.drop_after_add) {
+      if (g.addend) v += p.add;
+      v *= keep;
+    } else {
+      if (g.relu) v = fmaxf(v, 0.f);
+      v *= keep;
+      if (g.addend) v += p.add;
+    }
+  } else {
+    if (g.addend) v += p.add;
+    if (g.relu) v = fmaxf(v, 0.f);
+  }
+  if (g.mask) {
+    if (!(p.mask > 0.f)) v = 0.f;
+    else if (g.mask_scale != 0.f) v *= g.mask_scale;
+  }
+  return v;
+}
 __device__ __forceinline__ float keep_of(uint32_t bytes, int e, float scale) { return ((bytes >> (8 * e)) & 0xffu) ? scale : 0.f; }
 
 // (bx, by, bz) = the tile this workgroup owns: blockIdx of a single-job launch, or what the block map of a group launch says
@@ -266,6 +302,8 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
   const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
   f32x4 a[NCH], b[2][NCH];
   f32x4 xh[LN ? NCH : 1], gg[LN ? NCH : 1];
+  uint32_t kbs[LN ? NCH : 1];     // keep bytes of ln_drop: requested with everything else (a load behind the row statistics
+                                  // would put a memory round trip into the middle of every kernel of the sweep)
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = 4 * i + w, kk = 16 * c + 4 * kq;
@@ -274,6 +312,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     if constexpr (LN) {
       xh[i] = bl4(mk_rsrc(g.ln_xhat), (cok && mok) ? (unsigned)(m * (int)g.ld_ln + kk) * 4u : OOB);
       gg[i] = bl4(mk_rsrc(g.ln_g), cok ? (unsigned)kk * 4u : OOB);
+      kbs[i] = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(g.ln_drop), (g.ln_drop && cok && mok) ? (unsigned)(m * (int)g.ld_ln_drop + kk) : OOB, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -285,6 +324,14 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
 #pragma unroll
         for (int e = 0; e < 4; ++e) b[t][i][e] = bl1(rb, ok ? (unsigned)((kk + e) * (int)g.sbk + n) * 4u : OOB);
       }
+    }
+  }
+  EpiPre pre[ATT ? 1 : 2];
+  if constexpr (!ATT) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int mm = m0 + (tid >> 4), n = n0 + 16 * it + (tid & 15);
+      pre[it] = gemm_epi_load(g, mm, n, mm < g.M && n < g.N);
     }
   }
   // attention operands of (agent m0 + tid/16, head blockIdx.x), lane l16 = tid % 16
@@ -341,7 +388,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       if (blockIdx.x == 0 && g.ln_dx && c < nch && mok)
         *reinterpret_cast<f32x4 *>(g.ln_dx + (size_t)m * g.ld_ln + 16 * c + 4 * kq) = a[i];
       if (g.ln_drop) {     // the sub-layer's output was dropped before the residual add: its gradient is keep * A'
-        const uint32_t kb = (c < nch && mok) ? *reinterpret_cast<const uint32_t *>(g.ln_drop + (size_t)m * g.ld_ln_drop + 16 * c + 4 * kq) : 0u;
+        const uint32_t kb = kbs[i];          // (lanes beyond the rows / chunks loaded nothing: zeros)
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[i][e] *= keep_of(kb, e, g.ln_drop_scale);
         if (blockIdx.x == 0 && g.ln_dxm && c < nch && mok)
@@ -422,7 +469,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     const int mm = m0 + row, n = n0 + 16 * t + col;
     if (mm >= g.M || n >= g.N) continue;
     const int ix = row * 17 + col;
-    const float v = gemm_epi(g, ((red[0][t][ix] + red[1][t][ix]) + red[2][t][ix]) + red[3][t][ix], mm, n);
+    const float v = gemm_epi_pre(g, ((red[0][t][ix] + red[1][t][ix]) + red[2][t][ix]) + red[3][t][ix], pre[ATT ? 0 : it]);
     float *cp = g.C + (size_t)mm * g.ldc + n;
     *cp = g.accumulate ? (*cp + v) : v;
   }
