@@ -492,7 +492,14 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        # every rank has finished its collectives; leave without tearing the RCCL communicator down: that teardown has been seen
+        # to abort() a process (one-rank rehearsal under pytest, once in a handful of runs), which would turn a finished
+        # measurement into a failed launch
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -279,8 +279,17 @@ void launch_split(const mmt_gemm_args &g, hipStream_t st) {
 // first column block also store it (ln_dx) for the residual path and the deferred weight-gradient GEMMs.
 template <int DPL>
 __device__ __forceinline__ void ld_dpl(float (&dst)[DPL], rsrc_t r, unsigned off) {
+  if constexpr (DPL == 2) {        // one 8-byte load (the callers' offsets are even numbers of floats from 16-byte aligned bases)
+    // (bit_cast of whatever 8-byte type the builtin returns: assigning it to a 2 x u32 vector compiles as a splat of its low
+    // half, and the load shrinks to one dword)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    dst[0] = v[0];
+    dst[1] = v[1];
+  } else {
 #pragma unroll
-  for (int e = 0; e < DPL; ++e) dst[e] = bl1(r, off == OOB ? OOB : off + 4u * e);
+    for (int e = 0; e < DPL; ++e) dst[e] = bl1(r, off == OOB ? OOB : off + 4u * e);
+  }
 }
 // ATT = true (head dim 32, one query per agent: the decoder's per-step sweep): the 16 x 32 tile is the gradient at the output of
 // head blockIdx.x of an attention for 16 agents, and is consumed in place by that attention's backward (dq =, dK / dV +=, as
@@ -302,6 +311,8 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
   const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
   f32x4 a[NCH], b[2][NCH];
   f32x4 xh[LN ? NCH : 1], gg[LN ? NCH : 1];
+  float rstd = 0.f;               // (first of all loads: everything behind the row statistics is scaled by it)
+  if constexpr (LN) rstd = bl1(mk_rsrc(g.ln_rstd), mok ? (unsigned)m * 4u : OOB);
   uint32_t kbs[LN ? NCH : 1];     // keep bytes of ln_drop: requested with everything else (a load behind the row statistics
                                   // would put a memory round trip into the middle of every kernel of the sweep)
 #pragma unroll
@@ -334,9 +345,13 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       pre[it] = gemm_epi_load(g, mm, n, mm < g.M && n < g.N);
     }
   }
+  // (the loads are consumed in the order LayerNorm operands -> GEMM operands -> attention operands and return in issue order:
+  // keep the compiler from hoisting the ~110 attention loads in front of the operands the first stage waits for)
+  __builtin_amdgcn_sched_barrier(0);
   // attention operands of (agent m0 + tid/16, head blockIdx.x), lane l16 = tid % 16
   const int ab = m0 + (tid >> 4), l16 = tid & 15;
-  float kr[ATT ? 16 : 1][2], dkr[ATT ? 16 : 1][2], dvr[ATT ? 16 : 1][2], qd[2] = {0.f, 0.f}, pk = 0.f, pkeep = 1.f;
+  float kr[ATT ? 16 : 1][2], dkr[ATT ? 16 : 1][2], dvr[ATT ? 16 : 1][2], qd[2] = {0.f, 0.f}, pk = 0.f;
+  uint32_t pkeep_b = 0;      // keep byte of the probability this lane owns (a.pdrop)
   f32x4 vrow[ATT ? 8 : 1];
   int Lk = 0;
   if constexpr (ATT) {
@@ -356,10 +371,10 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     for (int c = 0; c < 8; ++c) vrow[c] = bl4(rv, l16 < Lk ? (vb + (unsigned)(l16 * (int)a.v_rs + 4 * c)) * 4u : OOB);
     ld_dpl<2>(qd, mk_rsrc(a.q), Lk > 0 ? (unsigned)(ab * (int)a.q_bs + h * 32 + l16 * 2) * 4u : OOB);
     pk = bl1(mk_rsrc(a.probs), l16 < Lk ? (unsigned)((ab * a.H + h) * (int)a.p_hs + l16) * 4u : OOB);
-    if (a.pdrop) pkeep = (l16 < Lk && a.pdrop[(size_t)(ab * a.H + h) * a.p_hs + l16]) ? a.pdrop_scale : 0.f;
+    pkeep_b = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pdrop), (a.pdrop && l16 < Lk) ? (unsigned)((ab * a.H + h) * (int)a.p_hs + l16) : OOB, 0, 0);
   }
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (LN) {
-    const float rstd = mok ? g.ln_rstd[m] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
@@ -420,6 +435,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     }
     __syncthreads();
     const mmt_attn_args &a = att.a;
+    const float pkeep = a.pdrop ? ((pkeep_b & 0xffu) ? a.pdrop_scale : 0.f) : 1.f;
     const float *grow = ct[tid >> 4];
     float dp = 0.f;
 #pragma unroll
@@ -1495,7 +1511,7 @@ extern "C" int mmt_attention_bwd(const mmt_attn_args *a, const float *d_o, long 
 #define BWD(KERNEL, DHV) hipLaunchKernelGGL(KERNEL<DHV>, grid, blk, 0, st, *a, d_o, do_bs, do_rs, dq, dq_bs, dq_rs, dk, dv, dk_bs, dk_rs)
   // register-resident variant: few keys, 8-byte aligned per-lane slices, offsets within the buffer descriptors' range
   const bool small = a->Lk <= 16 && a->dh <= 32 && ((uintptr_t)dk & 15) == 0 && ((uintptr_t)dv & 15) == 0 && (dk_bs & 3) == 0 &&
-                     (dk_rs & 3) == 0 &&
+                     (dk_rs & 3) == 0 && ((uintptr_t)a->k & 7) == 0 && ((a->k_bs | a->k_rs) & 1) == 0 &&
                      (double)a->B * (double)std::max(std::max(a->k_bs, a->v_bs), (int64_t)dk_bs) +
                              (double)a->Lk * (double)std::max(std::max(a->k_rs, a->v_rs), (int64_t)dk_rs) < 5e8;
   if (small && a->dh == 16) BWD(mmt_attn_bwd16_kernel, 16);

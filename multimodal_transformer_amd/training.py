@@ -1291,15 +1291,20 @@ class Trainer:
                 self._bwd_late()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # capture_error_mode "thread_local": with a process group up, ProcessGroupNCCL's watchdog thread queries its events
+        # whenever it likes; under the default "global" mode such a call from ANOTHER thread invalidates this thread's capture
+        # (seen on MI355X once in a handful of runs: the next launch fails and the watchdog aborts the process).  This thread
+        # itself only launches kernels while capturing.
+        mode = dict(capture_error_mode="thread_local")
         self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
+        with torch.cuda.graph(self._g_fb, **mode):
             self._fwd_bwd()
         if self.overlap:
             self._g_late = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_late):
+            with torch.cuda.graph(self._g_late, **mode):
                 self._bwd_late()
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt):
+        with torch.cuda.graph(self._g_opt, **mode):
             self._opt()
 
     def step(self, x_st, y_st, maps=None, lanes=None):
