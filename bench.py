@@ -272,11 +272,16 @@ def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, grou
                            f"broadcast from rank 0 at start" if world > 1 else "single GPU",
             "dropout": ({"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
                          "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
-                         "decode": ("mmt_decoder_forward_dropout: launch-per-phase 4-agent-cluster kernels reading the step's keep masks"
+                         "decode": (f"mmt_decoder_forward_dropout: {_last_decoder_path()}, reading the step's keep masks"
                                     if tr.engine._ar_decode_takes_masks() else
                                     "step by step on the stash kernels (tokens depend on the masks)")} if dropout else 0.0),
             "last_loss_rank0": float(loss),
             "algorithmic_tflops": 3 * (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * world * steps / elapsed / 1e12}
+
+
+def _last_decoder_path():
+    from multimodal_transformer_amd import ops
+    return ops.decoder_last_path()[1]
 
 
 def predict_fn(model, mode, dev, B, history, ph, seed):

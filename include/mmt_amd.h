@@ -332,9 +332,11 @@ int mmt_cnn_forward(const mmt_cnn *cnn, const float *maps, int B, float *out, fl
  * bytes the caller drew (mmt_dropout_mask), so that the positions fed back are the ones the training step's stash pass and
  * backward see.  Sites are laid out like the training step's stash: `pe`, `drop1/2/3[l]` (ph, B, d) step-major, `ff[l]`
  * (ph, B, d_ff), `attn1[l]` (B, H, ph, ph), `attn2[l]` (B, H, ph, T); a NULL site is not dropped; *_scale = 1/(1-p).
- * Runs on the launch-per-phase 4-agent-cluster kernels only (mmt_decoder_dropout_supported: head dimension 32, lin4 weight
- * copies present, batch small enough for 4-agent clusters -- B <= 128 on 256 CUs); otherwise MMT_EINVAL, and the caller decodes
- * step by step on the training kernels (training.py).  No teacher-forced form: with given tokens the stash pass is the decode. */
+ * Runs on the 4-agent-cluster kernels only (mmt_decoder_dropout_supported: head dimension 32, lin4 weight copies present, batch
+ * small enough for 4-agent clusters -- B <= 256 on 256 CUs): the one-launch pipeline's DROP instantiation where mmt_decoder_forward
+ * would take the pipeline, else the launch-per-phase kernels' (bit-identical to each other; the keep bytes of a visit are requested
+ * before its poll); otherwise MMT_EINVAL, and the caller decodes step by step on the training kernels (training.py).  No
+ * teacher-forced form: with given tokens the stash pass is the decode. */
 typedef struct {
   const uint8_t *pe;
   const uint8_t *attn1[MMT_MAX_LAYERS], *drop1[MMT_MAX_LAYERS], *attn2[MMT_MAX_LAYERS], *drop2[MMT_MAX_LAYERS],

@@ -243,6 +243,9 @@ __device__ __forceinline__ void ns_mfma_store(const NsW<NS_KMAX> &r, const float
 // ------------------------------------------------------------------------------- x = LN(res + bias + sum_g part[g])
 // 32 lanes per row, two float4 column groups per lane (d <= 256).  Summation order is fixed.
 // four keep bytes (one aligned 32-bit load) -> the factors 0 | scale of four consecutive columns
+__device__ __forceinline__ f32x4 keep4w(unsigned kb, float scale) {
+  return (f32x4){(kb & 0xffu) ? scale : 0.f, (kb & 0xff00u) ? scale : 0.f, (kb & 0xff0000u) ? scale : 0.f, (kb & 0xff000000u) ? scale : 0.f};
+}
 __device__ __forceinline__ f32x4 keep4(const uint8_t *p, size_t off, float scale) {
   const unsigned kb = *reinterpret_cast<const unsigned *>(p + off);
   return (f32x4){(kb & 0xffu) ? scale : 0.f, (kb & 0xff00u) ? scale : 0.f, (kb & 0xff0000u) ? scale : 0.f, (kb & 0xff000000u) ? scale : 0.f};
@@ -413,7 +416,10 @@ __device__ __forceinline__ void embed_pe(float (&pe)[2], const ClArgs &a, int s)
     pe[j] = bl1(mk_rsrc(a.pe + (size_t)s * a.d), slab < D16 ? (unsigned)(slab * 16 + (lane & 15)) * 4u : OOB);
   }
 }
-__device__ __forceinline__ void embed_token_res(const ClArgs &a, const EmbedW &E, const float (&pe)[2], const float *tok, float *xs, int ldx) {
+// kpe (DROP): keep bytes of the lane's 2 x 4 outputs, one word per slab (byte rr = row rr), loaded by embed_keep
+template <bool DROP = false>
+__device__ __forceinline__ void embed_token_res(const ClArgs &a, const EmbedW &E, const float (&pe)[2], const float *tok, float *xs, int ldx,
+                                                const unsigned (&kpe)[2] = {0u, 0u}) {
   const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
   const f32x4 xv = *reinterpret_cast<const f32x4 *>(tok + (lane & 15) * LDTOK + (lane >> 4) * 4);
 #pragma unroll
@@ -428,10 +434,29 @@ __device__ __forceinline__ void embed_token_res(const ClArgs &a, const EmbedW &E
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           float y = acc[rr] + add;
+          if constexpr (DROP) {
+            if (a.dk_pe) y = ((kpe[j] >> (8 * rr)) & 0xffu) ? y * a.ds_pe : 0.f;     // (rows beyond the batch are never read)
+          }
           if (a.tagged) y = tag1(y, (unsigned)a.s & TAG_MASK);
           xs[rr * ldx + slab * 16 + lane] = y;
         }
       }
+    }
+  }
+}
+
+// the keep bytes embed_token_res<true> applies: lane < 16 owns column slab*16 + lane of rows 0..3 (agents a0..a0+3)
+__device__ __forceinline__ void embed_keep(unsigned (&kpe)[2], const ClArgs &a, int a0, int na) {
+  const int lane = lane_id(), w = wave_id(), D16 = a.d >> 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int slab = w + CNW * j;
+    kpe[j] = 0u;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const unsigned v = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.dk_pe), (a.dk_pe && slab < D16 && lane < 16 && rr < na)
+                                                                 ? (unsigned)((a0 + rr) * a.d + slab * 16 + lane) : OOB, 0, 0);
+      kpe[j] |= (v & 0xffu) << (8 * rr);
     }
   }
 }
@@ -846,9 +871,11 @@ __device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int 
 // PAIRS (the reduction that follows the cross-attention phase): the parts are added two by two, each pair sum carrying the
 // producing phase's tag - exactly what the pipeline kernel's cross-attention workgroups, which own two heads each, hand over
 // as ONE pre-summed part (half the rows for its consumers to load); the forms stay bit-identical.
+// pre_keep (DROP): the row's four keep bytes, already loaded (the pipeline requests them before it polls: a load behind the poll
+// would be a memory round trip on every hop)
 template <int AUX = AUX_PLAIN, bool DROP = false, bool PAIRS = false>
 __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res,
-                                               bool tag_rows = true) {
+                                               bool tag_rows = true, const unsigned *pre_keep = nullptr) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
   f32x4 part[PAIRS ? 4 : 8];
@@ -873,7 +900,7 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
       f32x4 t = R.bias;
 #pragma unroll
       for (int g = 0; g < NPT; ++g) t += part[g];
-      acc = R.res + keep4(a.dk_red, (size_t)ag * a.d + 4 * q, a.ds_red) * t;
+      acc = R.res + (pre_keep ? keep4w(*pre_keep, a.ds_red) : keep4(a.dk_red, (size_t)ag * a.d + 4 * q, a.ds_red)) * t;
       dropped = true;
     }
   }
@@ -1416,8 +1443,10 @@ __device__ __forceinline__ float kparts_sum_rows(const f32x4 &acc) {
   if constexpr (CGW <= 2) v += dpp_mov<0x128>(v);
   return v;
 }
+// ff_keep >= 0 (phase C, training-mode dropout): the keep byte of the ONE hidden value this lane writes, ff_scale = 1/(1-p)
 template <int DH, int PHASE, int D, int FS>
-__device__ __forceinline__ void gemm1_4s(const MainRegs4<DH, PHASE> &M, const float *xs, int ldx, float *t1, int ld1) {
+__device__ __forceinline__ void gemm1_4s(const MainRegs4<DH, PHASE> &M, const float *xs, int ldx, float *t1, int ld1, int ff_keep = -1,
+                                         float ff_scale = 1.f) {
   typedef Geom4<PHASE> G4;
   typedef Lin4S<(PHASE == PH_C ? FS : DH) / 4, D / 4> L1;
   static_assert(L1::q <= G4::QMAX1, "first linear exceeds the register tile");
@@ -1445,7 +1474,9 @@ __device__ __forceinline__ void gemm1_4s(const MainRegs4<DH, PHASE> &M, const fl
   if constexpr (PHASE == PH_A) {
     if (bb < 3) t1[r * ld1 + bb * DH + w * 4 + j] = (bb == 0 ? tot[0] : bb == 1 ? tot[G4::NPART > 1 ? 1 : 0] : tot[G4::NPART > 2 ? 2 : 0]) + M.b1;
   } else if (bb < (PHASE == PH_C ? L1::cgw : 1)) {
-    t1[r * ld1 + (w * L1::cgw + bb) * 4 + j] = PHASE == PH_C ? fmaxf(tot[0] + M.b1, 0.f) : tot[0] + M.b1;
+    float v = PHASE == PH_C ? fmaxf(tot[0] + M.b1, 0.f) : tot[0] + M.b1;
+    if (PHASE == PH_C && ff_keep >= 0) v = ff_keep ? v * ff_scale : 0.f;
+    t1[r * ld1 + (w * L1::cgw + bb) * 4 + j] = v;
   }
 }
 // the accumulators of one second linear, K parts summed (every lane of a column group's blocks holds the total)
@@ -1529,6 +1560,7 @@ struct PipeArgs {
   const float *head_bias;                      // what the head stage's reduction adds / normalises with: the last layer's
   mmt_norm head_ln;                            //   linear2 bias and norm3
   int nlayers, test_stall, R, NHW, NC, pad_;
+  mmt_decoder_dropout drop;                    // DROP instantiation only: the training step's keep-byte sites
 };
 constexpr int PIPE_MAXPOS = 16;                // clusters whose last positions a head workgroup keeps in LDS (others: pred_st)
 
@@ -1648,7 +1680,7 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
 // zeros and meet probabilities that are zeros: no select per key (16 lane masks = 32 spilled SGPRs in this kernel)
 template <int DH, int PHASE, bool ZEROED = false>
 __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const float *t1, int ld1, const float *Ks, const float *Vs,
-                                        float *ps, float *ob, int visit = 0) {
+                                        float *ps, float *ob, int visit = 0, int att_keep = -1) {
   constexpr int LDK = DH + 4;
   const int nglob = PHASE == PH_A ? a.s : a.T;
   const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
@@ -1675,6 +1707,7 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
   float p = mx > -INFINITY ? expf(sc - mx) : 0.f;    // a fully masked row yields zeros (reference: undefined / NaN)
   const float sum = row16_sum(p);
   p *= sum > 0.f ? 1.0f / sum : 0.f;
+  if (att_keep >= 0 && !masked) p = att_keep ? p * a.ds_att : 0.f;      // dropout on the probabilities (as phase4_body<DROP>)
   ps[lane] = p;
   PSTAMP(visit, 9);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // ps is written and read by this wave only
@@ -1713,7 +1746,7 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
 // One visit of a stage workgroup to one cluster: NH heads / slices starting at g0, weights already in M.
 // kv_ready: M[].kv / pad already hold this visit's K/V cache rows (requested during the previous visit); nx_*: the next visit,
 // whose rows are requested behind this visit's attention (nx_cluster < 0: none, or they are not final yet).
-template <int DH, int PHASE, int NH, int D, int FS>
+template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false>
 __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, int cluster, int g0, bool loadx, const PipeLds &S,
                                            const PipeSync &ps, MainRegs4<DH, PHASE> (&M)[NH], int &pad, bool kv_ready, int nx_step,
                                            int nx_cluster, int visit) {
@@ -1743,6 +1776,27 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   Red4Regs R;
   const bool red_wave = wave_id() < 4;
   bool got = true;
+  // training-mode dropout: this visit's keep bytes do not depend on the previous phase either -- requested before the poll
+  // (branch-free: a load under a branch makes the compiler wait for everything in flight where the branch rejoins)
+  unsigned k_red = 0u, kb_ff = 0u, kb_att = 0u;
+  bool on_ff = false, on_att = false;
+  if constexpr (DROP) {
+    if (red_wave && !loadx) {
+      const int ag = a0 + wave_id();
+      k_red = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(a.dk_red), (a.dk_red && lane_id() < (d >> 2) && ag < a.B)
+                                                       ? (unsigned)(ag * d + 4 * lane_id()) : OOB, 0, 0);
+    }
+    if constexpr (PHASE == PH_C) {      // gemm1_4s: lane (DPP row r, in-row block bb, j) writes hidden column (w*cgw + bb)*4 + j of row r
+      constexpr int cgw = (FS / 4) >> 3;
+      const int b = lane_id() >> 2, j = lane_id() & 3, r = b >> 2, bb = b & 3;
+      on_ff = a.dk_ff && bb < cgw && r < na;
+      kb_ff = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.dk_ff), on_ff ? (unsigned)((a0 + r) * (FS * a.H) + g0 * FS + (wave_id() * cgw + bb) * 4 + j) : OOB, 0, 0);
+    } else {
+      const int ar = lane_id() >> 4, l16 = lane_id() & 15, Lk = PHASE == PH_A ? a.ph : a.T;
+      on_att = a.dk_att && wave_id() < NH && ar < na && l16 < (PHASE == PH_A ? a.s + 1 : a.T);
+      kb_att = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.dk_att), on_att ? (unsigned)(((a0 + ar) * a.H + g0 + wave_id()) * a.ph * Lk + l16) : OOB, 0, 0);
+    }
+  }
   if (red_wave) {
     if (!loadx) {
       const unsigned co = lane_id() < (d >> 2) ? (unsigned)lane_id() * 16u : OOB;
@@ -1763,7 +1817,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
         if (g0 == 0) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + wave_id()) * d), (unsigned)lane_id() * 16u, tag4(R.res, tag_out));
       }
     } else {
-      reduce4_finish<AUX>(R, a, cluster, S.xs, ldx, g0 == 0);
+      reduce4_finish<AUX, DROP>(R, a, cluster, S.xs, ldx, g0 == 0, true, DROP ? &k_red : nullptr);
     }
   }
   // K/V cache rows (the self-attention cache was appended by this very workgroup in earlier steps): registers -> staging tiles
@@ -1786,7 +1840,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   PSTAMP(visit, 2);
   // ---- 3. first linear
 #pragma unroll
-  for (int h = 0; h < NH; ++h) gemm1_4s<DH, PHASE, D, FS>(M[h], S.xs, ldx, S.t1 + h * 4 * LD1, LD1);
+  for (int h = 0; h < NH; ++h) gemm1_4s<DH, PHASE, D, FS>(M[h], S.xs, ldx, S.t1 + h * 4 * LD1, LD1, (DROP && on_ff) ? (int)(kb_ff & 0xffu) : -1, a.ds_ff);
   PSTAMP(visit, 7);
   __syncthreads();
   PSTAMP(visit, 3);
@@ -1795,7 +1849,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
     if (wave_id() < NH) {
       const int h = wave_id();
       attend4<DH, PHASE, PIPE_ATT_ZEROED>(a, na, pad_now, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
-                         S.ob + h * 4 * LDO, visit);
+                         S.ob + h * 4 * LDO, visit, (DROP && on_att) ? (int)(kb_att & 0xffu) : -1);
     } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read back by this workgroup only)
       const int i = tid - 256;
       if (i < na * 2 * (DH / 4)) {
@@ -1827,7 +1881,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   return true;
 }
 
-template <int DH, int PHASE, int NH, int D, int FS>
+template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false>
 __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0, int replica, const PipeLds &S, const PipeSync &ps) {
   static_assert(PHASE != PH_A || NH == 1, "the K/V cache append serves one head");
   ClArgs a = f.a;
@@ -1870,6 +1924,22 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
     a.xres_out = f.xres[p & 1] + rb_out;
     a.part_in = f.part[(p + 1) & 1] + rb_in;
     a.xres_in = f.xres[(p + 1) & 1] + rb_in;
+    if constexpr (DROP) {      // this step's keep-byte sites, as launch_phases' drop_of gives them to the launch-per-phase kernels
+      const mmt_decoder_dropout &Dr = f.drop;
+      const size_t Bd = (size_t)f.a.B * f.a.d, Bf = (size_t)f.a.B * FS * f.a.H;
+      auto site = [](const uint8_t *base, size_t off) -> const uint8_t * { return base ? base + off : nullptr; };
+      a.dk_red = a.dk_pe = a.dk_ff = a.dk_att = nullptr;
+      if constexpr (PHASE == PH_A) {
+        if (layer > 0) a.dk_red = site(Dr.drop3[layer - 1], (size_t)s * Bd), a.ds_red = Dr.drop3_scale[layer - 1];
+        a.dk_att = site(Dr.attn1[layer], (size_t)s * f.a.ph), a.ds_att = Dr.attn1_scale[layer];
+      } else if constexpr (PHASE == PH_B) {
+        a.dk_red = site(Dr.drop1[layer], (size_t)s * Bd), a.ds_red = Dr.drop1_scale[layer];
+        a.dk_att = site(Dr.attn2[layer], (size_t)s * f.a.T), a.ds_att = Dr.attn2_scale[layer];
+      } else {
+        a.dk_red = site(Dr.drop2[layer], (size_t)s * Bd), a.ds_red = Dr.drop2_scale[layer];
+        a.dk_ff = site(Dr.ff[layer], (size_t)s * Bf), a.ds_ff = Dr.ff_scale[layer];
+      }
+    }
     int li = 0;
 #pragma clang loop unroll(disable)
     for (int m = replica; m < f.NC; m += f.R, ++li) {
@@ -1879,7 +1949,7 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
         if (m + f.R < f.NC) nx_cluster = m + f.R;
         else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
       }
-      if (!pipe_phase<DH, PHASE, NH, D, FS>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li)) return;
+      if (!pipe_phase<DH, PHASE, NH, D, FS, DROP>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li)) return;
       kv_ready = nx_cluster >= 0;
     }
   }
@@ -1887,7 +1957,7 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
 
 // The head workgroups: head of the previous step (s > 0) and embedding of the next token, for the clusters
 // replica + R * (j + NHW * i), i = 0, 1, ...  The token rows go to x0buf (tag s & 1), a buffer of their own.
-template <int CPW>
+template <int CPW, bool DROP = false>
 __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j, const PipeLds &S, const PipeSync &ps) {
   ClArgs a = f.a;
   const int d = a.d, ldx = d + MMT_PAD, K16 = d >> 4, tid = thread_idx();
@@ -1936,6 +2006,13 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
     const size_t rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
     a.part_in = f.part[(p + 1) & 1] + rb_in;
     a.xres_in = f.xres[(p + 1) & 1] + rb_in;
+    if constexpr (DROP) {      // dropout3 of the last layer at the step the head consumes; the positional encoder's at this step
+      const size_t Bd = (size_t)a.B * a.d;
+      a.dk_red = (f.drop.drop3[f.nlayers - 1] && s > 0) ? f.drop.drop3[f.nlayers - 1] + (size_t)(s - 1) * Bd : nullptr;
+      a.ds_red = f.drop.drop3_scale[f.nlayers - 1];
+      a.dk_pe = f.drop.pe ? f.drop.pe + (size_t)s * Bd : nullptr;
+      a.ds_pe = f.drop.pe_scale;
+    }
     int li = 0;
 #pragma clang loop unroll(disable)
     for (int m = replica + j * f.R; m < f.NC; m += f.R * f.NHW, ++li) {
@@ -1943,6 +2020,15 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
       PSTAMP(s * 4096 + li, 0);
       Red4Regs R;
       const bool red_wave = s > 0 && wave_id() < 4;
+      unsigned k_red = 0u, kpe[2] = {0u, 0u};
+      if constexpr (DROP) {
+        if (red_wave) {
+          const int ag = a0 + wave_id();
+          k_red = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(a.dk_red), (a.dk_red && lane_id() < (d >> 2) && ag < a.B)
+                                                           ? (unsigned)(ag * d + 4 * lane_id()) : OOB, 0, 0);
+        }
+        embed_keep(kpe, a, a0, na);
+      }
       if (red_wave) {
         const unsigned co = lane_id() < (d >> 2) ? (unsigned)lane_id() * 16u : OOB;
         R.bias = bl4(mk_rsrc(a.red_bias), co);
@@ -1953,7 +2039,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
       PSTAMP(s * 4096 + li, 1);
       __syncthreads();
       if (*ps.abort) return;
-      if (red_wave) reduce4_finish<AUX_SC1>(R, a, m, S.xs, ldx, false, false);
+      if (red_wave) reduce4_finish<AUX_SC1, DROP>(R, a, m, S.xs, ldx, false, false, DROP ? &k_red : nullptr);
       if (s > 0) head_step<CPW>(a, 0, a0, na, S.xs, ldx, S.red, S.ha, S.hb, S.tok, wo, sm0, li < PIPE_MAXPOS ? S.pos + li * 64 : nullptr);
       if (a.tgt || s == 0)
         for (int i = tid; i < na * a.n_in; i += CNT) {
@@ -1962,7 +2048,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         }
       __syncthreads();
       PSTAMP(s * 4096 + li, 4);
-      embed_token_res(a, emb, pe, S.tok, S.xs, ldx);         // rows tagged s & 1
+      embed_token_res<DROP>(a, emb, pe, S.tok, S.xs, ldx, kpe);         // rows tagged s & 1
       __syncthreads();
       PSTAMP(s * 4096 + li, 5);
       if (wave_id() < 4 && lane_id() < (d >> 2))       // the embedded token, write-through, 16 bytes per lane
@@ -1974,7 +2060,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
   }
 }
 
-template <int DH, int CPW, int D, int FS>
+template <int DH, int CPW, int D, int FS, bool DROP = false>
 __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
   extern __shared__ __align__(16) float smem[];
   const PipeLds S = pipe_lds<DH>(smem, f.a.d);
@@ -1987,11 +2073,11 @@ __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
   __syncthreads();
   if (rb < f.nlayers * per_layer) {
     const int layer = rb / per_layer, q = rb - layer * per_layer;
-    if (q < H) pipe_stage<DH, PH_A, 1, D, FS>(f, layer, q, replica, S, ps);
-    else if (q < H + H / 2) pipe_stage<DH, PH_B, 2, D, FS>(f, layer, 2 * (q - H), replica, S, ps);
-    else pipe_stage<DH, PH_C, 1, D, FS>(f, layer, q - H - H / 2, replica, S, ps);
+    if (q < H) pipe_stage<DH, PH_A, 1, D, FS, DROP>(f, layer, q, replica, S, ps);
+    else if (q < H + H / 2) pipe_stage<DH, PH_B, 2, D, FS, DROP>(f, layer, 2 * (q - H), replica, S, ps);
+    else pipe_stage<DH, PH_C, 1, D, FS, DROP>(f, layer, q - H - H / 2, replica, S, ps);
   } else {
-    pipe_head<CPW>(f, replica, rb - f.nlayers * per_layer, S, ps);
+    pipe_head<CPW, DROP>(f, replica, rb - f.nlayers * per_layer, S, ps);
   }
 }
 
@@ -2330,8 +2416,12 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
     if constexpr (M4) {
       (void)hipFuncSetAttribute((const void *)mmt_dec_fused4_kernel<DH, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
       if constexpr (DH == 32 && CPW == 2)
+      {
         (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+      }
     }
     ds.attr_mask.fetch_or(fam_bit, std::memory_order_release);
   }
@@ -2404,8 +2494,11 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         f.R = pg.R;
         f.NHW = pg.NHW;
         f.NC = NC;
-        if constexpr (DH == 32 && CPW == 2)      // the pipeline is built for the shipped geometry (pipe_geom_ok): d = 256, d_ff / H = 64
-          hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64>), dim3(pg.grid), blk, pipe_lds_floats<32>(256) * sizeof(float), st, f);
+        if (drop) f.drop = *drop;
+        if constexpr (DH == 32 && CPW == 2) {    // the pipeline is built for the shipped geometry (pipe_geom_ok): d = 256, d_ff / H = 64
+          if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true>), dim3(pg.grid), blk, pipe_lds_floats<32>(256) * sizeof(float), st, f);
+          else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64>), dim3(pg.grid), blk, pipe_lds_floats<32>(256) * sizeof(float), st, f);
+        }
         p = 3 * L * ph;
       } else {
         FusedArgs f;
@@ -2476,7 +2569,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 }
 
 // The one-launch kernel spins on its siblings: it is only started when the occupancy query says the whole grid is resident.
-static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d) {
+static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool drop = false) {
   constexpr int DH = 32;
   constexpr int LD1 = 3 * DH + 8;
   const size_t lds = pipe ? pipe_lds_floats<DH>(d) * sizeof(float)
@@ -2484,7 +2577,8 @@ static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d) {
                              (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
   int per_cu = 0;
   hipError_t e;
-  if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64>, CNT, lds);
+  if (pipe && drop) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, CNT, lds);
+  else if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64>, CNT, lds);
   else e = cpw2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 2>, CNT, lds)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 1>, CNT, lds);
   if (e != hipSuccess) {
@@ -2542,7 +2636,8 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
     if (!mmt_cluster_decoder_dropout_ok(dec, B) || tgt)
       return mmt_set_error(MMT_EINVAL, "mmt_decoder_forward_dropout: only the autoregressive decode on the 4-agent-cluster kernels "
                                        "(head dimension 32, lin4 weight copies, batch small enough for 4-agent clusters) takes keep masks");
-    allow_fused = 0;                // the launch-per-phase kernels are the ones instantiated with the mask reads
+    // the launch-per-phase kernels and the pipeline are instantiated with the mask reads, the fused kernel is not
+    allow_fused = (allow_fused == 2 || allow_fused == 3) ? 2 : 0;
   }
   float *memkv = workspace;
   float *selfkv = memkv + (size_t)L * B * T * 2 * d;
@@ -2567,7 +2662,7 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   PipeGeom pg = {0, 0, 0, nullptr};
   if (allow_fused != 0 && m4 && !dec_env().no_fused && !g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) {
     if (d == 256 && dec->d_ff == 64 * H) pg = pipe_geom(L, H, NC, ncu);      // the geometry the pipeline kernel is compiled for
-    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d)) one_launch = ONE_LAUNCH_PIPE;
+    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d, drop != nullptr)) one_launch = ONE_LAUNCH_PIPE;
     else if (allow_fused != 2 && NC * H <= ncu && one_launch_fits(false, d > 128, NC * H, ncu, d)) one_launch = ONE_LAUNCH_FUSED;
   }
   const bool fuse_phases = one_launch != ONE_LAUNCH_NONE;

@@ -285,9 +285,10 @@ def test_vit_training_step_with_its_dropouts_matches_restatement_autograd():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["basic", "map_cnn", "lane_cnn", "basic-140"])
 def test_masked_autoregressive_decode_equals_the_step_by_step_decode(mode):
-    """With dropout the tokens fed back depend on the masks.  At the shipped geometry the inference decoder's launch-per-phase
-    kernels read the step's keep bytes (mmt_decoder_forward_dropout); everywhere else the engine decodes step by step on the
-    stash kernels.  Same seed, same masks: both must give the same positions, loss and gradients."""
+    """With dropout the tokens fed back depend on the masks.  At the shipped geometry the inference decoder's one-launch pipeline
+    and its launch-per-phase kernels read the step's keep bytes (mmt_decoder_forward_dropout); everywhere else the engine decodes
+    step by step on the stash kernels.  Same seed, same masks: all three must give the same positions, loss and gradients, the
+    two inference forms bit for bit."""
     from multimodal_transformer_amd import ops, training
     from multimodal_transformer_amd.weights import apply_recipe
     dev = _gdev()
@@ -300,18 +301,29 @@ def test_masked_autoregressive_decode_equals_the_step_by_step_decode(mode):
     apply_recipe(reg.model_dict, seed=0)
     t = {k: torch.from_numpy(v).to(dev) for k, v in batch_for(mode, False, B).items()}
     out = []
-    for masked in (True, False):
-        eng = training.TrainEngine(model, B, t["x_st"].shape[1], ph, seed=21)
-        assert eng.drop.active and eng._ar_decode_takes_masks()
-        if not masked:
-            eng._ar_masks_ok = False
-        eng.set_batch(t["x_st"], t["y_st"], t.get("map"), t.get("lanes"))
-        loss = float(eng.forward())
-        if masked:
-            assert ops.decoder_last_path()[0] == 3          # MMT_PATH_CLUSTER_LAUNCHES4: the kernels that read the masks
-        eng.backward()
-        out.append((loss, eng.predictions().clone(), eng.flat_grad.clone(), eng.drop.pool.clone()))
-    assert torch.equal(out[0][3], out[1][3])                                   # the very same masks
-    assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[1][0])
-    assert rel_err(out[0][1].cpu().numpy(), out[1][1].cpu().numpy()) <= 1e-5
-    assert rel_err(out[0][2].cpu().numpy(), out[1][2].cpu().numpy()) <= 1e-4
+    try:
+        # masked decode on the one-launch pipeline (AUTO picks it at this geometry; its DROP instantiation), on the launch-per-phase
+        # kernels, and the step-by-step decode on the stash kernels
+        for form in ("auto", "cluster_launches", None):
+            ops.decoder_select(form or "auto")
+            eng = training.TrainEngine(model, B, t["x_st"].shape[1], ph, seed=21)
+            assert eng.drop.active and eng._ar_decode_takes_masks()
+            if form is None:
+                eng._ar_masks_ok = False
+            eng.set_batch(t["x_st"], t["y_st"], t.get("map"), t.get("lanes"))
+            loss = float(eng.forward())
+            if form == "auto":
+                assert ops.decoder_last_path()[0] == 5      # MMT_PATH_CLUSTER_PIPELINE (every size here is within its 256 agents)
+            elif form == "cluster_launches":
+                assert ops.decoder_last_path()[0] == 3      # MMT_PATH_CLUSTER_LAUNCHES4
+            ops.decoder_status()
+            eng.backward()
+            out.append((loss, eng.predictions().clone(), eng.flat_grad.clone(), eng.drop.pool.clone()))
+    finally:
+        ops.decoder_select("auto")
+    assert torch.equal(out[0][3], out[2][3]) and torch.equal(out[1][3], out[2][3])          # the very same masks
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])   # pipeline == launches, bit for bit
+    for o in out[:2]:
+        assert abs(o[0] - out[2][0]) <= 1e-5 * abs(out[2][0])
+        assert rel_err(o[1].cpu().numpy(), out[2][1].cpu().numpy()) <= 1e-5
+        assert rel_err(o[2].cpu().numpy(), out[2][2].cpu().numpy()) <= 1e-4
