@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <stdint.h>
 #include "../../include/mmt_amd.h"
 
@@ -709,6 +710,109 @@ __global__ __launch_bounds__(256) void mmt_ln_fwd_kernel(const float *__restrict
   if (lane == 0) rstd_out[row] = rstd;
 }
 
+// The same two kernels with the row in registers (N = 64 * NPL columns): every load of a row is requested at once and the row is
+// read once instead of three times (the generic forms above walk it per pass: three dependent memory round trips in a kernel
+// that 31 + 24 launches of a training step sit behind).  Same element-to-lane assignment, same order of additions: same bits.
+// Contraction is switched off in both and every fused multiply-add is written out, in the places where the compiler fuses in the
+// generic forms: a contraction the compiler is free to pick differently here (it did: d0*d0 + d1*d1 fused the other way round, the
+// constant 1/N folded into the subtraction) moves a result by an ulp, and the full-size gradient test against the reference's
+// autograd sits on exactly those ulps after 12 feedback steps.
+template <int NPL>
+__global__ __launch_bounds__(256) void mmt_ln_fwd_regs_kernel(const float *__restrict__ x, const float *__restrict__ res, int M,
+                                                              const float *__restrict__ g, const float *__restrict__ b, int relu,
+                                                              float *__restrict__ y, float *__restrict__ xhat,
+                                                              float *__restrict__ rstd_out) {
+#pragma clang fp contract(off)
+  constexpr int N = 64 * NPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const size_t o = (size_t)row * N;
+  float v[NPL], gg[NPL], bb[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) v[i] = x[o + lane + 64 * i];
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] += res[o + lane + 64 * i];
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) gg[i] = g[lane + 64 * i], bb[i] = b[lane + 64 * i];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) s += v[i];
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k, 64);
+  const float mu = s * (1.0f / (float)N);        // (N is a power of two: the quotient, exactly)
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const float d = v[i] - mu;
+    q = fmaf(d, d, q);
+  }
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) q += __shfl_xor(q, k, 64);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / (float)N) + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const float h = (v[i] - mu) * rstd;
+    float out = fmaf(h, gg[i], bb[i]);
+    if (relu) out = fmaxf(out, 0.f);
+    y[o + lane + 64 * i] = out;
+    xhat[o + lane + 64 * i] = h;
+  }
+  if (lane == 0) rstd_out[row] = rstd;
+}
+template <int NPL>
+__global__ __launch_bounds__(256) void mmt_ln_bwd_regs_kernel(const float *__restrict__ dy, const float *__restrict__ xhat,
+                                                              const float *__restrict__ rstd, const float *__restrict__ g,
+                                                              const float *__restrict__ y_relu, int M, float *__restrict__ dx,
+                                                              int accumulate, float *__restrict__ dy_masked,
+                                                              const uint8_t *__restrict__ drop, float drop_scale,
+                                                              float *__restrict__ dxm) {
+#pragma clang fp contract(off)
+  constexpr int N = 64 * NPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const size_t o = (size_t)row * N;
+  float d[NPL], xh[NPL], gg[NPL], old[NPL];
+  uint8_t kp[NPL];
+  const float rs = rstd[row];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const size_t c = o + lane + 64 * i;
+    d[i] = dy[c];
+    xh[i] = xhat[c];
+    gg[i] = g[lane + 64 * i];
+    old[i] = accumulate ? dx[c] : 0.f;
+    kp[i] = drop ? drop[c] : (uint8_t)1;
+  }
+  if (y_relu) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+      if (!(y_relu[o + lane + 64 * i] > 0.f)) d[i] = 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    if (dy_masked) dy_masked[o + lane + 64 * i] = d[i];
+    const float dg = d[i] * gg[i];
+    s1 += dg;
+    s2 += dg * xh[i];
+  }
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) {
+    s1 += __shfl_xor(s1, k, 64);
+    s2 += __shfl_xor(s2, k, 64);
+  }
+  const float m1 = s1 * (1.0f / (float)N), m2 = s2 * (1.0f / (float)N);
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const size_t c = o + lane + 64 * i;
+    const float v = rs * fmaf(-xh[i], m2, fmaf(d[i], gg[i], -m1));
+    dx[c] = accumulate ? old[i] + v : v;
+    if (drop) dxm[c] = kp[i] ? v * drop_scale : 0.f;
+  }
+}
+
 // dx (+)= rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * g [masked where y <= 0 if relu];
 // the masked dy is written to dy_masked (may alias dy) for the deferred parameter-gradient reduction.
 __global__ __launch_bounds__(256) void mmt_ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ xhat,
@@ -817,6 +921,67 @@ __global__ __launch_bounds__(256) void mmt_attn_fwd_kernel(mmt_attn_args a) {
 #pragma unroll
       for (int e = 0; e < DPL; ++e) o[e] = fmaf(pj, V[(size_t)j * a.v_rs + l16 * DPL + e], o[e]);
     }
+  }
+  if (live) {
+    float *out = a.o + (size_t)b * a.o_bs + (size_t)i * a.o_rs + h * DH + l16 * DPL;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) out[e] = o[e];
+  }
+}
+
+// The same for <= 16 keys with every operand requested at kernel entry (the form above loads the pad byte, then the key row under
+// that branch, then - behind the softmax - the keep byte and one value row per key under a branch on its probability: a dozen
+// dependent memory round trips, 9.9 us per launch at 1536 x 8 queries).  Same arithmetic in the same order: same bits.
+template <int DH>
+__global__ __launch_bounds__(256) void mmt_attn_fwd16_kernel(mmt_attn_args a) {
+  constexpr int NQ = DH / 4, DPL = DH / 16;
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l16 = threadIdx.x & 15;
+  const bool live = grp < a.B * a.H * a.Lq;
+  const int gq = live ? grp : 0;
+  const int i = gq % a.Lq, h = (gq / a.Lq) % a.H, b = gq / (a.Lq * a.H);
+  const int nk = !live ? 0 : a.causal ? min(i + 1 + a.causal_offset, a.Lk) : a.Lk;
+  const rsrc_t rq = mk_rsrc(a.q), rk = mk_rsrc(a.k), rv = mk_rsrc(a.v);
+  const bool kin = l16 < nk;
+  const unsigned qo = (unsigned)(b * (int)a.q_bs + i * (int)a.q_rs + h * DH), ko = (unsigned)(b * (int)a.k_bs + l16 * (int)a.k_rs + h * DH);
+  const unsigned vo = (unsigned)(b * (int)a.v_bs + h * DH + l16 * DPL), po = (unsigned)((b * a.H + h) * (int)a.p_hs + i * (int)a.p_rs + l16);
+  f32x4 qv[NQ], kv[NQ];
+#pragma unroll
+  for (int c = 0; c < NQ; ++c) {
+    qv[c] = bl4(rq, live ? (qo + 4u * c) * 4u : OOB);
+    kv[c] = bl4(rk, kin ? (ko + 4u * c) * 4u : OOB);
+  }
+  const unsigned padb = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pad), (a.pad && kin) ? (unsigned)(b * a.Lk + l16) : OOB, 0, 0);
+  const unsigned pdb = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(a.pdrop), (a.pdrop && live && l16 < a.Lk) ? po : OOB, 0, 0);
+  float vv[16][DPL];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ld_dpl<DPL>(vv[j], rv, j < nk ? (vo + (unsigned)(j * (int)a.v_rs)) * 4u : OOB);
+  float sc = -INFINITY;
+  if (kin && !(padb & 0xffu)) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+      acc = fmaf(qv[c][0], kv[c][0], acc);
+      acc = fmaf(qv[c][1], kv[c][1], acc);
+      acc = fmaf(qv[c][2], kv[c][2], acc);
+      acc = fmaf(qv[c][3], kv[c][3], acc);
+    }
+    sc = acc * a.scale;
+  }
+  const float mx = row16_max(sc);
+  float p0 = mx > -INFINITY ? expf(sc - mx) : 0.f;
+  const float sum = row16_sum(p0);
+  p0 *= sum > 0.f ? 1.0f / sum : 0.f;
+  if (live && l16 < a.Lk) a.probs[po] = p0;
+  if (a.pdrop) p0 *= (l16 < a.Lk && (pdb & 0xffu)) ? a.pdrop_scale : 0.f;     // the stash keeps the softmax; the output uses keep * softmax
+  float o[DPL];
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float pj = __shfl(p0, j, 16);
+    const bool on = j < nk && pj > 0.f;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) o[e] = on ? fmaf(pj, vv[j][e], o[e]) : o[e];
   }
   if (live) {
     float *out = a.o + (size_t)b * a.o_bs + (size_t)i * a.o_rs + h * DH + l16 * DPL;
@@ -1239,6 +1404,12 @@ __global__ void mmt_lr_step_kernel(float *state, float gamma, const float *guard
 
 }  // namespace
 
+// diagnostic switches, read once: MMT_TRAIN_GENERIC bit 0 = generic LayerNorm forward, 1 = generic LayerNorm backward, 2 = generic
+// attention forward (A/B of the register-resident / burst forms against the forms they replaced)
+static int train_generic() {
+  static const int v = getenv("MMT_TRAIN_GENERIC") ? atoi(getenv("MMT_TRAIN_GENERIC")) : 0;
+  return v;
+}
 static int launch_ok(const char *what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return mmt_set_error(MMT_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -1460,8 +1631,15 @@ extern "C" int mmt_colsum(const float *a, const float *b, const float *mask, int
 extern "C" int mmt_layernorm_fwd(const float *x, const float *res, int M, int N, const float *g, const float *b, int relu,
                                  float *y, float *xhat, float *rstd, void *stream) {
   if (!x || !g || !b || !y || !xhat || !rstd || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_layernorm_fwd: bad arguments");
-  hipLaunchKernelGGL(mmt_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, res, M, N, g, b, relu, y, xhat,
-                     rstd);
+  const dim3 grid((M + 3) / 4), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  // (y / xhat may alias x or res element for element - each lane reads its elements before it writes them)
+  if (train_generic() & 1) hipLaunchKernelGGL(mmt_ln_fwd_kernel, grid, blk, 0, st, x, res, M, N, g, b, relu, y, xhat, rstd);
+  else if (N == 256) hipLaunchKernelGGL(mmt_ln_fwd_regs_kernel<4>, grid, blk, 0, st, x, res, M, g, b, relu, y, xhat, rstd);
+  else if (N == 128) hipLaunchKernelGGL(mmt_ln_fwd_regs_kernel<2>, grid, blk, 0, st, x, res, M, g, b, relu, y, xhat, rstd);
+  else if (N == 64) hipLaunchKernelGGL(mmt_ln_fwd_regs_kernel<1>, grid, blk, 0, st, x, res, M, g, b, relu, y, xhat, rstd);
+  else if (N == 512) hipLaunchKernelGGL(mmt_ln_fwd_regs_kernel<8>, grid, blk, 0, st, x, res, M, g, b, relu, y, xhat, rstd);
+  else hipLaunchKernelGGL(mmt_ln_fwd_kernel, grid, blk, 0, st, x, res, M, N, g, b, relu, y, xhat, rstd);
   return launch_ok("mmt_layernorm_fwd");
 }
 
@@ -1471,7 +1649,18 @@ extern "C" int mmt_layernorm_bwd(const float *dy, const float *xhat, const float
   if (!dy || !xhat || !rstd || !g || !dx || M <= 0 || N <= 0) return mmt_set_error(MMT_EINVAL, "mmt_layernorm_bwd: bad arguments");
   if ((drop != nullptr) != (dx_dropped != nullptr) || (drop && accumulate))
     return mmt_set_error(MMT_EINVAL, "mmt_layernorm_bwd: drop and dx_dropped go together, and not with accumulate");
-  hipLaunchKernelGGL(mmt_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, g, y_relu, M, N,
+  const dim3 grid((M + 3) / 4), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LN_BWD_REGS(NPL) hipLaunchKernelGGL(mmt_ln_bwd_regs_kernel<NPL>, grid, blk, 0, st, dy, xhat, rstd, g, y_relu, M, dx, accumulate, dy_masked, drop, drop_scale, dx_dropped)
+  if (train_generic() & 2) hipLaunchKernelGGL(mmt_ln_bwd_kernel, grid, blk, 0, st, dy, xhat, rstd, g, y_relu, M, N,
+                     dx, accumulate, dy_masked, drop, drop_scale, dx_dropped);
+  else if (N == 256) LN_BWD_REGS(4);
+  else if (N == 128) LN_BWD_REGS(2);
+  else if (N == 64) LN_BWD_REGS(1);
+  else if (N == 512) LN_BWD_REGS(8);
+  else
+#undef LN_BWD_REGS
+  hipLaunchKernelGGL(mmt_ln_bwd_kernel, grid, blk, 0, st, dy, xhat, rstd, g, y_relu, M, N,
                      dx, accumulate, dy_masked, drop, drop_scale, dx_dropped);
   return launch_ok("mmt_layernorm_bwd");
 }
@@ -1493,7 +1682,16 @@ extern "C" int mmt_attention_fwd(const mmt_attn_args *a, void *stream) {
   const int total = a->B * a->H * a->Lq;                 // groups of 16 lanes
   const dim3 grid((total + 15) / 16), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (a->dh == 16) hipLaunchKernelGGL(mmt_attn_fwd_kernel<16>, grid, blk, 0, st, *a);
+  // <= 16 keys and offsets within a buffer descriptor's range: every operand in one burst
+  const double qmax = (double)a->B * (double)a->q_bs + (double)a->Lq * (double)a->q_rs;
+  const double kmax = (double)a->B * (double)std::max(a->k_bs, a->v_bs) + (double)a->Lk * (double)std::max(a->k_rs, a->v_rs);
+  const double pmax = (double)a->B * a->H * (double)a->p_hs + (double)a->Lq * (double)a->p_rs;
+  const bool burst = !(train_generic() & 4) && a->Lk <= 16 && qmax < 5e8 && kmax < 5e8 && pmax < 5e8 && a->q_bs >= 0 && a->q_rs >= 0 && a->k_bs >= 0 &&
+                     a->k_rs >= 0 && a->v_bs >= 0 && a->v_rs >= 0;
+  if (burst && a->dh == 16) hipLaunchKernelGGL(mmt_attn_fwd16_kernel<16>, grid, blk, 0, st, *a);
+  else if (burst && a->dh == 32) hipLaunchKernelGGL(mmt_attn_fwd16_kernel<32>, grid, blk, 0, st, *a);
+  else if (burst) hipLaunchKernelGGL(mmt_attn_fwd16_kernel<64>, grid, blk, 0, st, *a);
+  else if (a->dh == 16) hipLaunchKernelGGL(mmt_attn_fwd_kernel<16>, grid, blk, 0, st, *a);
   else if (a->dh == 32) hipLaunchKernelGGL(mmt_attn_fwd_kernel<32>, grid, blk, 0, st, *a);
   else hipLaunchKernelGGL(mmt_attn_fwd_kernel<64>, grid, blk, 0, st, *a);
   return launch_ok("mmt_attention_fwd");
