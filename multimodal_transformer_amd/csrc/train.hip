@@ -301,16 +301,19 @@ struct RowsAttn {
   float *dq, *dk, *dv;
   long dq_bs, dk_bs, dk_rs;
 };
-template <int NCH, bool BK, bool LN, bool ATT = false>
+// NT: 16-column tiles per workgroup (2 = the 16 x 32 tile above; 1 = 16 x 16: twice the workgroups, half the B operand loads
+// and MFMAs per wave; at K > 256 a wave of the 16 x 32 form has more loads in flight than the 63 its counter can track)
+template <int NCH, bool BK, bool LN, bool ATT = false, int NT = 2>
 __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, RowsAttn att) {
-  __shared__ float red[4][2][16 * 17];
+  static_assert(!ATT || NT == 2, "a head is 32 columns wide");
+  __shared__ float red[4][NT][16 * 17];
   __shared__ float stat[4][16][2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32, nch = g.K >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16 * NT, nch = g.K >> 4;
   const int m = m0 + l15;
   const bool mok = m < g.M;
   const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
-  f32x4 a[NCH], b[2][NCH];
+  f32x4 a[NCH], b[NT][NCH];
   f32x4 xh[LN ? NCH : 1], gg[LN ? NCH : 1];
   float rstd = 0.f;               // (first of all loads: everything behind the row statistics is scaled by it)
   if constexpr (LN) rstd = bl1(mk_rsrc(g.ln_rstd), mok ? (unsigned)m * 4u : OOB);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       kbs[i] = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(g.ln_drop), (g.ln_drop && cok && mok) ? (unsigned)(m * (int)g.ld_ln_drop + kk) : OOB, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int n = n0 + 16 * t + l15;
       const bool ok = cok && n < g.N;
       if constexpr (BK) {
@@ -338,10 +341,10 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       }
     }
   }
-  EpiPre pre[ATT ? 1 : 2];
+  EpiPre pre[ATT ? 1 : NT];
   if constexpr (!ATT) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NT; ++it) {
       const int mm = m0 + (tid >> 4), n = n0 + 16 * it + (tid & 15);
       pre[it] = gemm_epi_load(g, mm, n, mm < g.M && n < g.N);
     }
@@ -412,18 +415,20 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
       }
     }
   }
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     if (4 * i + w < nch) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[t][i][e], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[t][i][e], acc[t], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][t][(4 * kq + r) * 17 + l15] = acc[t][r];
   __syncthreads();
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     return;
   }
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < NT; ++it) {
     const int o = tid + 256 * it, t = o >> 8, row = (o & 255) >> 4, col = o & 15;
     const int mm = m0 + row, n = n0 + 16 * t + col;
     if (mm >= g.M || n >= g.N) continue;
@@ -494,11 +499,22 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
 
 template <bool BK, bool LN>
 void launch_rows(const mmt_gemm_args &g, hipStream_t st) {
-  const dim3 grid((g.N + 31) / 32, (g.M + 15) / 16), blk(256);
+  const dim3 grid((g.N + 31) / 32, (g.M + 15) / 16), grid1((g.N + 15) / 16, (g.M + 15) / 16), blk(256);
   const RowsAttn none = {};
-  if (g.K <= 256) hipLaunchKernelGGL((mmt_gemm_rows_kernel<4, BK, LN>), grid, blk, 0, st, g, none);
-  else if (g.K <= 512) hipLaunchKernelGGL((mmt_gemm_rows_kernel<8, BK, LN>), grid, blk, 0, st, g, none);
-  else hipLaunchKernelGGL((mmt_gemm_rows_kernel<12, BK, LN>), grid, blk, 0, st, g, none);
+  // 16 x 16 tiles where that still fits the chip in one round (the sweep's GEMMs at <= 256 rows: 4.06 against 5.64 us at K = 768,
+  // 3.19 / 4.27 at K = 512, 2.35 / 3.05 at K = 256, back to back in a graph)
+  static const int nt1_mode = getenv("MMT_ROWS_NT1") ? atoi(getenv("MMT_ROWS_NT1")) : 2;      // 0: never, 1: K > 256, 2: every K (measured best)
+  const bool nt1 = (nt1_mode == 2 || (nt1_mode == 1 && !LN && g.K > 256)) && (long)grid1.x * grid1.y <= 256;
+  if (g.K <= 256) {
+    if (nt1) hipLaunchKernelGGL((mmt_gemm_rows_kernel<4, BK, LN, false, 1>), grid1, blk, 0, st, g, none);
+    else hipLaunchKernelGGL((mmt_gemm_rows_kernel<4, BK, LN>), grid, blk, 0, st, g, none);
+  } else if (g.K <= 512) {
+    if (nt1) hipLaunchKernelGGL((mmt_gemm_rows_kernel<8, BK, LN, false, 1>), grid1, blk, 0, st, g, none);
+    else hipLaunchKernelGGL((mmt_gemm_rows_kernel<8, BK, LN>), grid, blk, 0, st, g, none);
+  } else {
+    if (nt1) hipLaunchKernelGGL((mmt_gemm_rows_kernel<12, BK, LN, false, 1>), grid1, blk, 0, st, g, none);
+    else hipLaunchKernelGGL((mmt_gemm_rows_kernel<12, BK, LN>), grid, blk, 0, st, g, none);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ thin GEMM

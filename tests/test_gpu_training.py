@@ -762,3 +762,4 @@ def test_a_step_whose_decode_gave_up_leaves_the_weights_alone():
     assert bool(torch.isfinite(loss).all()) and tr.skipped_steps() == 1
     assert any(not torch.equal(p.detach(), q) for (_, p), q in zip(tr.engine.named_params, before))
     ops.decoder_status()
+    lib.mmt_debug_decoder_stall(0)        # re-arm the one-launch forms for the tests that follow (the status query switched them off)
