@@ -79,7 +79,8 @@ def time_kernels(model, reg, tensors, ph, iters):
     out = {}
 
     def avg(fn):
-        fn()
+        for _ in range(3):
+            fn()
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
         for a, b in evs:
@@ -87,7 +88,10 @@ def time_kernels(model, reg, tensors, ph, iters):
             fn()
             b.record()
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in evs) / iters
+        # median: an iteration in which the host fell behind the GPU (its start event is stamped before the launches arrive)
+        # or the clocks had not ramped yet is not the kernels' time
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return ts[len(ts) // 2]
 
     memory, pad = enc.forward_with_mask(x_st)
     start = x_st[:, -1, 0:2].contiguous()
