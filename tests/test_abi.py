@@ -97,3 +97,36 @@ def test_batch_error_reporting_helpers(capsys):
     with pytest.raises(NotImplementedError):
         log_batch_errors(batches, w, "eval", 7, bar_plot=["kde"])
     assert np.isclose(w.scalars["VEHICLE/eval/ade_median"][0], 3.0)
+
+
+def test_group_launch_planner_validates_jobs_and_lays_out_the_table():
+    """mmt_gemm_group_plan / mmt_ln_grad_group_plan are host-only: sizes, the block map, and a job the group kernel does not take."""
+    lib = _lib.load()
+    jobs = (_lib.GemmArgs * 2)()
+    for j, (M, N, K) in zip(jobs, ((64, 96, 1536), (36, 32, 1000))):        # dY^T X forms: A (M,K) and B (K,N) with unit stride in M / N
+        j.A, j.sam, j.sak = 0x1000, 1, M
+        j.B, j.sbk, j.sbn = 0x2000, N, 1
+        j.C, j.ldc, j.M, j.N, j.K = 0x3000, N, M, N, K
+        j.splitk, j.part_stride = 4, 1 << 20
+    nbytes, nblocks = ctypes.c_size_t(0), ctypes.c_int(0)
+    assert lib.mmt_gemm_group_plan(jobs, 2, None, 0, ctypes.byref(nbytes), ctypes.byref(nblocks)) == 0
+    assert nblocks.value == (2 * 3 + 2 * 1) * 4 and nbytes.value == 2 * ctypes.sizeof(_lib.GemmArgs) + 16 * nblocks.value
+    buf = (ctypes.c_uint8 * nbytes.value)()
+    assert lib.mmt_gemm_group_plan(jobs, 2, buf, nbytes.value - 1, ctypes.byref(nbytes), ctypes.byref(nblocks)) != 0     # too small
+    assert lib.mmt_gemm_group_plan(jobs, 2, buf, nbytes.value, ctypes.byref(nbytes), ctypes.byref(nblocks)) == 0
+    assert bytes(buf[:2 * ctypes.sizeof(_lib.GemmArgs)]) == bytes(jobs)
+    blocks = (ctypes.c_int32 * (4 * nblocks.value)).from_buffer_copy(bytes(buf[2 * ctypes.sizeof(_lib.GemmArgs):]))
+    rows = [tuple(blocks[4 * i:4 * i + 4]) for i in range(nblocks.value)]
+    assert rows[0] == (0, 0, 0, 0) and rows[-1] == (1, 0, 1, 3) and len(set(rows)) == len(rows)
+    assert sum(1 for r in rows if r[0] == 0) == 24
+    jobs[1].relu = 1                                            # an epilogue: not a split-K weight-gradient job
+    assert lib.mmt_gemm_group_plan(jobs, 2, None, 0, ctypes.byref(nbytes), ctypes.byref(nblocks)) != 0
+    assert b"job 1" in lib.mmt_last_error()
+    assert lib.mmt_gemm_group(None, 2, 8, None) != 0 and lib.mmt_ln_grad_group(None, 1, 1, None) != 0
+    ln = (_lib.LnGradJob * 1)()
+    ln[0].dy, ln[0].xhat, ln[0].gw, ln[0].gb = 0x1000, 0x2000, 0x3000, 0x4000
+    ln[0].ld, ln[0].part_stride, ln[0].M, ln[0].N, ln[0].splitk = 256, 1 << 20, 1536, 256, 4
+    assert lib.mmt_ln_grad_group_plan(ln, 1, None, 0, ctypes.byref(nbytes), ctypes.byref(nblocks)) == 0
+    assert nblocks.value == 16 * 4 and nbytes.value == ctypes.sizeof(_lib.LnGradJob) + 16 * 64
+    ln[0].splitk = 0
+    assert lib.mmt_ln_grad_group_plan(ln, 1, None, 0, ctypes.byref(nbytes), ctypes.byref(nblocks)) != 0
