@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <cstdlib>
 #include <stdint.h>
 #include "../../include/mmt_amd.h"
@@ -532,6 +533,32 @@ __global__ __launch_bounds__(256) void mmt_gemm_thin_kernel(mmt_gemm_args g) {
     const float v = gemm_epi(g, s, m, n);
     float *cp = g.C + (size_t)m * g.ldc + n;
     *cp = g.accumulate ? (*cp + v) : v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ GEMM with a handful of k (K <= 8)
+// The head's last Linear has 2 outputs: its input gradient is a K = 2 product per step of the sweep (12 dependent launches per
+// training step, 6.8 us each on the generic tile kernel below).  One output per thread, every operand requested at once, the
+// same k-ordered chain of fused multiply-adds the matrix-core kernels run.
+__global__ __launch_bounds__(256) void mmt_gemm_smallk_kernel(mmt_gemm_args g) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = o < g.M * g.N;
+  const int m = ok ? o / g.N : 0, n = ok ? o - m * g.N : 0;
+  const rsrc_t ra = mk_rsrc(g.A), rb = mk_rsrc(g.B);
+  float a[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = bl1(ra, (ok && k < g.K) ? (unsigned)(m * (int)g.sam + k * (int)g.sak) * 4u : OOB);
+    b[k] = bl1(rb, (ok && k < g.K) ? (unsigned)(k * (int)g.sbk + n * (int)g.sbn) * 4u : OOB);
+  }
+  const EpiPre pre = gemm_epi_load(g, m, n, ok);
+  const float old = bl1(mk_rsrc(g.C), (ok && g.accumulate) ? (unsigned)(m * (int)g.ldc + n) * 4u : OOB);
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc = k < g.K ? fmaf(a[k], b[k], acc) : acc;
+  if (ok) {
+    const float v = gemm_epi_pre(g, acc, pre);
+    g.C[(size_t)m * g.ldc + n] = g.accumulate ? old + v : v;
   }
 }
 
@@ -1474,6 +1501,13 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
     if (ak && bk) big ? launch_panel<64, true, true>(*g, st) : launch_panel<32, true, true>(*g, st);
     else if (ak) big ? launch_panel<64, true, false>(*g, st) : launch_panel<32, true, false>(*g, st);
     else big ? launch_panel<64, false, false>(*g, st) : launch_panel<32, false, false>(*g, st);
+    return launch_ok("mmt_gemm");
+  }
+  if (g->K <= 8 && (long)g->M * g->N <= (1 << 20) && !g->ln_xhat && std::abs((double)g->M * (double)g->sam) + 8.0 * std::abs((double)g->sak) < 5e8 &&
+      std::abs((double)g->N * (double)g->sbn) + 8.0 * std::abs((double)g->sbk) < 5e8 && (double)g->M * (double)g->ldc < 5e8 &&
+      g->sam >= 0 && g->sak >= 0 && g->sbk >= 0 && g->sbn >= 0 && (!g->addend || (double)g->M * (double)g->ld_add < 5e8) &&
+      (!g->mask || (double)g->M * (double)g->ld_mask < 5e8) && (!g->drop || (double)g->M * (double)g->ld_drop < 2e9)) {
+    hipLaunchKernelGGL(mmt_gemm_smallk_kernel, dim3((unsigned)(((long)g->M * g->N + 255) / 256)), dim3(256), 0, st, *g);
     return launch_ok("mmt_gemm");
   }
   if ((long)g->M * g->N <= 2048 && g->K >= 256) {
