@@ -526,13 +526,27 @@ __global__ __launch_bounds__(256) void mmt_gemm_thin_kernel(mmt_gemm_args g) {
   if (o >= g.M * g.N) return;
   const int m = o / g.N, n = o - m * g.N;
   const float *A = g.A + (size_t)m * g.sam, *B = g.B + (size_t)n * g.sbn;
+  // epilogue operands and the old output first, the reduction's loads eight per lane at a time (a rolled loop waits for every
+  // load before it issues the next, and the epilogue's loads came behind the wave sum: six dependent round trips at K = 256)
+  const EpiPre pre = gemm_epi_load(g, m, n, lane == 0);
+  const float old = (lane == 0 && g.accumulate) ? g.C[(size_t)m * g.ldc + n] : 0.f;
   float s = 0.f;
-  for (int k = lane; k < g.K; k += 64) s = fmaf(A[(size_t)k * g.sak], B[(size_t)k * g.sbk], s);
+  for (int k0 = lane; k0 < g.K; k0 += 512) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 + 64 * i;
+      const bool in = k < g.K;
+      av[i] = in ? A[(size_t)k * g.sak] : 0.f;
+      bv[i] = in ? B[(size_t)k * g.sbk] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = (k0 + 64 * i < g.K) ? fmaf(av[i], bv[i], s) : s;
+  }
   s = wave64_sum(s);
   if (lane == 0) {
-    const float v = gemm_epi(g, s, m, n);
-    float *cp = g.C + (size_t)m * g.ldc + n;
-    *cp = g.accumulate ? (*cp + v) : v;
+    const float v = gemm_epi_pre(g, s, pre);
+    g.C[(size_t)m * g.ldc + n] = g.accumulate ? (old + v) : v;
   }
 }
 
@@ -804,7 +818,8 @@ __global__ __launch_bounds__(256) void mmt_ln_fwd_regs_kernel(const float *__res
   }
   if (lane == 0) rstd_out[row] = rstd;
 }
-template <int NPL>
+// HALF: N = 32 (the head's hidden width): lanes 0..31 hold the row, the others zeros (as the generic form's idle lanes do)
+template <int NPL, bool HALF = false>
 __global__ __launch_bounds__(256) void mmt_ln_bwd_regs_kernel(const float *__restrict__ dy, const float *__restrict__ xhat,
                                                               const float *__restrict__ rstd, const float *__restrict__ g,
                                                               const float *__restrict__ y_relu, int M, float *__restrict__ dx,
@@ -812,31 +827,33 @@ __global__ __launch_bounds__(256) void mmt_ln_bwd_regs_kernel(const float *__res
                                                               const uint8_t *__restrict__ drop, float drop_scale,
                                                               float *__restrict__ dxm) {
 #pragma clang fp contract(off)
-  constexpr int N = 64 * NPL;
+  static_assert(!HALF || NPL == 1, "HALF is the 32-column form");
+  constexpr int N = HALF ? 32 : 64 * NPL;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const size_t o = (size_t)row * N;
   float d[NPL], xh[NPL], gg[NPL], old[NPL];
   uint8_t kp[NPL];
   const float rs = rstd[row];
+  const bool act = !HALF || lane < 32;
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const size_t c = o + lane + 64 * i;
-    d[i] = dy[c];
-    xh[i] = xhat[c];
-    gg[i] = g[lane + 64 * i];
-    old[i] = accumulate ? dx[c] : 0.f;
-    kp[i] = drop ? drop[c] : (uint8_t)1;
+    d[i] = act ? dy[c] : 0.f;
+    xh[i] = act ? xhat[c] : 0.f;
+    gg[i] = act ? g[lane + 64 * i] : 0.f;
+    old[i] = (act && accumulate) ? dx[c] : 0.f;
+    kp[i] = (act && drop) ? drop[c] : (uint8_t)1;
   }
   if (y_relu) {
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
-      if (!(y_relu[o + lane + 64 * i] > 0.f)) d[i] = 0.f;
+      if (act && !(y_relu[o + lane + 64 * i] > 0.f)) d[i] = 0.f;
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
-    if (dy_masked) dy_masked[o + lane + 64 * i] = d[i];
+    if (dy_masked && act) dy_masked[o + lane + 64 * i] = d[i];
     const float dg = d[i] * gg[i];
     s1 += dg;
     s2 += dg * xh[i];
@@ -851,8 +868,10 @@ __global__ __launch_bounds__(256) void mmt_ln_bwd_regs_kernel(const float *__res
   for (int i = 0; i < NPL; ++i) {
     const size_t c = o + lane + 64 * i;
     const float v = rs * fmaf(-xh[i], m2, fmaf(d[i], gg[i], -m1));
-    dx[c] = accumulate ? old[i] + v : v;
-    if (drop) dxm[c] = kp[i] ? v * drop_scale : 0.f;
+    if (act) {
+      dx[c] = accumulate ? old[i] + v : v;
+      if (drop) dxm[c] = kp[i] ? v * drop_scale : 0.f;
+    }
   }
 }
 
@@ -1708,6 +1727,7 @@ extern "C" int mmt_layernorm_bwd(const float *dy, const float *xhat, const float
   else if (N == 128) LN_BWD_REGS(2);
   else if (N == 64) LN_BWD_REGS(1);
   else if (N == 512) LN_BWD_REGS(8);
+  else if (N == 32) hipLaunchKernelGGL((mmt_ln_bwd_regs_kernel<1, true>), grid, blk, 0, st, dy, xhat, rstd, g, y_relu, M, dx, accumulate, dy_masked, drop, drop_scale, dx_dropped);
   else
 #undef LN_BWD_REGS
   hipLaunchKernelGGL(mmt_ln_bwd_kernel, grid, blk, 0, st, dy, xhat, rstd, g, y_relu, M, N,
