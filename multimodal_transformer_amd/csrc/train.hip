@@ -76,6 +76,7 @@ __device__ __forceinline__ EpiPre gemm_epi_load(const mmt_gemm_args &g, int m, i
   return p;
 }
 __device__ __forceinline__ float gemm_epi_pre(const mmt_gemm_args &g, float v, const EpiPre &p) {
+#pragma clang fp contract(off)      // keep * x and + addend stay two roundings (as torch's separate dropout and add kernels)
   if (g.bias) v += p.bias;
   if (g.drop) {
     const float keep = (p.keep & 0xffu) ? g.drop_scale : 0.f;
@@ -195,19 +196,38 @@ __device__ __forceinline__ void gemm_panel_body(mmt_gemm_args g, const int bx, c
     if (c + 1 < nc) sstore((c + 1) & 1);
     __syncthreads();
   }
+  // Epilogue: the operands of ALL of the thread's outputs are requested first (branch-free, out-of-range offsets for absent ones),
+  // then applied.  With a load per output under the bounds branches the compiler waited for each one in turn: up to 4 dependent
+  // round trips per output, 16 outputs per thread - most of the run time of the all-steps GEMMs of a training step.
+  // (offsets fit 32 bits: the dispatcher sends only operands below 5e8 floats here)
+  EpiPre pre[WT][WT][4];
+  float oldc[WT][WT][4];
+  const rsrc_t rc = mk_rsrc(g.C);
 #pragma unroll
   for (int i = 0; i < WT; ++i)
 #pragma unroll
     for (int j = 0; j < WT; ++j) {
       const int n = n0 + wn + 16 * j + (lane & 15);
-      if (n >= g.N) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
-        if (m >= g.M) continue;
-        const float v = gemm_epi(g, acc[i][j][r], m, n);
-        float *cp = g.C + (size_t)m * g.ldc + n;
-        *cp = g.accumulate ? (*cp + v) : v;
+        const bool ok = n < g.N && m < g.M;
+        pre[i][j][r] = gemm_epi_load(g, m, n, ok);
+        oldc[i][j][r] = bl1(rc, (ok && g.accumulate) ? (unsigned)(m * (int)g.ldc + n) * 4u : OOB);
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int n = n0 + wn + 16 * j + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + r;
+        if (n < g.N && m < g.M) {
+          const float v = gemm_epi_pre(g, acc[i][j][r], pre[i][j][r]);
+          g.C[(size_t)m * g.ldc + n] = g.accumulate ? (oldc[i][j][r] + v) : v;
+        }
       }
     }
   if constexpr (SPLIT && !AK) {
@@ -1478,6 +1498,14 @@ static int launch_ok(const char *what) {
   return MMT_OK;
 }
 
+// the kernels that request their epilogue operands through buffer descriptors address them with 32-bit byte offsets
+static bool epi32_ok(const mmt_gemm_args *g) {
+  const double M = (double)g->M;
+  return g->ldc >= 0 && M * (double)g->ldc + g->N < 5e8 && (!g->addend || (g->ld_add >= 0 && M * (double)g->ld_add + g->N < 5e8)) &&
+         (!g->mask || (g->ld_mask >= 0 && M * (double)g->ld_mask + g->N < 5e8)) &&
+         (!g->drop || (g->ld_drop >= 0 && M * (double)g->ld_drop + g->N < 2e9));
+}
+
 extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
   if (!g || !g->A || !g->B || !g->C) return mmt_set_error(MMT_EINVAL, "mmt_gemm: null pointer");
   if (g->M <= 0 || g->N <= 0 || g->K <= 0) return mmt_set_error(MMT_EINVAL, "mmt_gemm: empty problem %dx%dx%d", g->M, g->N, g->K);
@@ -1501,7 +1529,7 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
     return launch_ok("mmt_gemm");
   }
   // row-block kernel: few rows, whole K per workgroup (the dependent chain of the backward sweep)
-  const bool rows_ok = aligned && ak && g->K % 16 == 0 && g->K <= 768 && g->M <= 256 && amax < 5e8 && bmax < 5e8 &&
+  const bool rows_ok = aligned && ak && g->K % 16 == 0 && g->K <= 768 && g->M <= 256 && amax < 5e8 && bmax < 5e8 && epi32_ok(g) &&
                        (bk || (g->sbn == 1));
   if (g->ln_xhat) {
     if (!rows_ok || !g->ln_rstd || !g->ln_g || g->ld_ln % 4 || ((uintptr_t)g->ln_xhat & 15) || ((uintptr_t)g->ln_dx & 15) ||
@@ -1515,7 +1543,7 @@ extern "C" int mmt_gemm(const mmt_gemm_args *g, void *stream) {
     bk ? launch_rows<true, false>(*g, st) : launch_rows<false, false>(*g, st);
     return launch_ok("mmt_gemm");
   }
-  if (aligned && (ak || ar) && (bk || br) && !(ar && !ak && bk) && amax < 5e8 && bmax < 5e8) {
+  if (aligned && (ak || ar) && (bk || br) && !(ar && !ak && bk) && amax < 5e8 && bmax < 5e8 && epi32_ok(g)) {
     const bool big = ((g->M + 63) / 64) * ((g->N + 63) / 64) >= 128;
     if (ak && bk) big ? launch_panel<64, true, true>(*g, st) : launch_panel<32, true, true>(*g, st);
     else if (ak) big ? launch_panel<64, true, false>(*g, st) : launch_panel<32, true, false>(*g, st);
