@@ -563,19 +563,23 @@ def test_grouped_weight_gradient_launch_is_bit_identical_to_one_launch_per_gradi
     b = make_batch(B, 8, 12, seed=7, with_map=(mode == "map_cnn"), with_lanes=(mode == "lane_cnn"))
     t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
     out = []
-    for grouped in (True, False, True):
+    for grouped, same_slices in ((True, True), (False, True), (True, True), (True, False)):
         hp = make_hyperparams(mode, history=8, horizon=12)
         model, reg = _model(hp, dev)
         apply_recipe(reg.model_dict, seed=4)
         eng = training.TrainEngine(model, B, 9, 12, dropout=False)
         eng.group_wgrads = grouped
+        if same_slices:                       # the group launch with the K slices of the single launches: the very same sums
+            eng.GROUP_SPLITK = eng.SPLITK
         eng.set_batch(t["x_st"], t["y_st"], maps=t.get("map"), lanes=t.get("lanes"))
         loss = float(eng.forward())
         eng.backward()
         out.append((loss, eng.flat_grad.clone()))
     assert np.isfinite(out[0][0]) and float(out[0][1].abs().max()) > 0
-    assert out[0][0] == out[1][0] == out[2][0]
+    assert out[0][0] == out[1][0] == out[2][0] == out[3][0]
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1], out[2][1])
+    # the default group launch walks each K range in one piece: other partial sums, same gradients to rounding
+    assert rel_err(out[3][1].cpu().numpy(), out[1][1].cpu().numpy()) <= 1e-5
 
 
 def test_autograd_entry_point_on_device():

@@ -1,5 +1,5 @@
 """Profiling workload: N Basic training steps at batch B (rocprofv3 --kernel-trace target), eager (no graph) so that every
-kernel shows up by name.  python tools/train_only.py [B] [N] [dropout 0/1] [graph 0/1] [sweep ways] [grouped weight gradients 0/1]"""
+kernel shows up by name.  python tools/train_only.py [B] [N] [dropout 0/1] [graph 0/1] [sweep ways] [grouped weight gradients 0/1] [weight-gradient K slices]"""
 import os
 import sys
 import time
@@ -25,6 +25,8 @@ if len(sys.argv) > 5:
     tr.engine.sweep_ways = int(sys.argv[5])
 if len(sys.argv) > 6:
     tr.engine.group_wgrads = bool(int(sys.argv[6]))
+if len(sys.argv) > 7:
+    tr.engine.SPLITK = int(sys.argv[7])          # K slices of the weight-gradient GEMMs (1: no mirrors to sum)
 for _ in range(3):
     tr.step(x_st, y_st)
 torch.cuda.synchronize()
