@@ -299,6 +299,19 @@ void launch_split(const mmt_gemm_args &g, hipStream_t st) {
 // LN = true: the A operand is the gradient at a LayerNorm output; its LayerNorm backward (row statistics over the K
 // columns: the workgroup holds whole rows) is applied in registers before the multiply, and the workgroups of the
 // first column block also store it (ln_dx) for the residual path and the deferred weight-gradient GEMMs.
+// lane j of every 16-lane row, to all lanes of that row (j a compile-time constant after unrolling)
+__device__ __forceinline__ float row16_bcast(float v, int j) {
+  const int x = __builtin_bit_cast(int, v);
+  int r;
+  switch (j & 15) {
+#define MMT_BC(J) case J: r = __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xF, 0xF, false); break;
+    MMT_BC(0) MMT_BC(1) MMT_BC(2) MMT_BC(3) MMT_BC(4) MMT_BC(5) MMT_BC(6) MMT_BC(7)
+    MMT_BC(8) MMT_BC(9) MMT_BC(10) MMT_BC(11) MMT_BC(12) MMT_BC(13) MMT_BC(14)
+#undef MMT_BC
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x15F, 0xF, 0xF, false); break;
+  }
+  return __builtin_bit_cast(float, r);
+}
 template <int DPL>
 __device__ __forceinline__ void ld_dpl(float (&dst)[DPL], rsrc_t r, unsigned off) {
   if constexpr (DPL == 2) {        // one 8-byte load (the callers' offsets are even numbers of floats from 16-byte aligned bases)
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(256) void mmt_gemm_rows_kernel(mmt_gemm_args g, Row
     const float pkd = pk * pkeep;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {          // masked / absent keys carry p = ds = 0: exact no-ops
-      const float pj = __shfl(pkd, j, 16), dsj = __shfl(ds, j, 16);
+      const float pj = row16_bcast(pkd, j), dsj = row16_bcast(ds, j);      // (DPP row_newbcast: no trip through the LDS crossbar)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         dqa[e] = fmaf(dsj, kr[j][e], dqa[e]);
@@ -1060,7 +1073,7 @@ __global__ __launch_bounds__(256) void mmt_attn_fwd16_kernel(mmt_attn_args a) {
   for (int e = 0; e < DPL; ++e) o[e] = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const float pj = __shfl(p0, j, 16);
+    const float pj = row16_bcast(p0, j);
     const bool on = j < nk && pj > 0.f;
 #pragma unroll
     for (int e = 0; e < DPL; ++e) o[e] = on ? fmaf(pj, vv[j][e], o[e]) : o[e];
@@ -1206,7 +1219,7 @@ __global__ __launch_bounds__(256) void mmt_attn_bwd16_kernel(mmt_attn_args a, co
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {       // masked / absent keys carry p = ds = 0: the updates are exact no-ops
-      const float pj = __shfl(pdrop, j, 16), dsj = __shfl(ds, j, 16);
+      const float pj = row16_bcast(pdrop, j), dsj = row16_bcast(ds, j);
 #pragma unroll
       for (int e = 0; e < DPL; ++e) {
         dqa[e] = fmaf(dsj, kr[j][e], dqa[e]);
