@@ -57,15 +57,18 @@ def build_model(mode, dev, history, horizon):
     return hp, model, reg
 
 
-def kernel_source_hash():
-    """sha256 over the kernel sources: profile summaries under profiles/ record it, so that a stale one is never quoted."""
+PREDICT_SOURCES = ("decoder_cluster.hip", "transformer.hip", "encoder_split.hip", "mmt_device.cuh", "mmt_gfx950.cuh")
+
+
+def kernel_source_hash(names=PREDICT_SOURCES):
+    """sha256 over the sources of the predict path's kernels (encoder + decoder; the training / context kernels live in other
+    files): the traffic summary under profiles/ records it, so that a stale one is never quoted."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "multimodal_transformer_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".cuh")):
-            with open(os.path.join(csrc, name), "rb") as f:
-                h.update(name.encode())
-                h.update(f.read())
+    for name in sorted(names):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode())
+            h.update(f.read())
     return h.hexdigest()[:16]
 
 
