@@ -715,6 +715,28 @@ def test_lane_decoder_and_positional_encoding_match_stock_modules(B, Lq, T, d, H
     assert torch.equal(y.cpu(), mem + pe.pe[:T].cpu())
 
 
+@pytest.mark.parametrize("dropout", [0, 1])
+def test_register_resident_training_kernels_are_bit_identical_to_the_generic_forms(tmp_path, dropout):
+    """LayerNorm forward / backward with the row in registers and the burst-load attention forward against the generic forms they
+    replace (MMT_TRAIN_GENERIC=7 switches those back in; the library reads it once, hence two child processes): every stash
+    tensor and every gradient of a full-size step, bit for bit -- the contraction of these kernels is pinned by hand because the
+    full-size gradient test against the reference's autograd moved from 4e-4 to 1.5e-3 on one-ulp differences here."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ab_train_forms.py")
+    outs = []
+    for generic in ("0", "7"):
+        out = tmp_path / f"forms_{generic}.pt"
+        env = dict(os.environ, MMT_TRAIN_GENERIC=generic)
+        r = subprocess.run([sys.executable, tool, str(out), str(dropout)], capture_output=True, text=True, timeout=110, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(out))
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) > 50
+    bad = [k for k in outs[0] if not torch.equal(outs[0][k], outs[1][k])]
+    assert not bad, bad[:10]
+    assert float(outs[0]["grad"].abs().max()) > 0
+
+
 def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
     """The multi-rank step on one GPU: a one-rank RCCL group, the flat gradient all-reduce issued eagerly between the two HIP-graph
     replays (bench.py --gpus N runs exactly this with N ranks).  A one-rank sum changes nothing: losses and weights equal a run

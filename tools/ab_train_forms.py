@@ -1,5 +1,8 @@
+"""One full-size Basic training step (forward + backward), every stash tensor and the gradient saved: python tools/ab_train_forms.py
+out.pt [dropout 0/1].  Run under MMT_TRAIN_GENERIC=0 / 7 to compare the register-resident LayerNorm / burst attention kernels with the
+generic forms (tests/test_gpu_training.py does)."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_model
 from multimodal_transformer_amd.synthetic import make_batch
 from multimodal_transformer_amd.training import TrainEngine
