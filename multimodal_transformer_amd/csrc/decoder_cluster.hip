@@ -541,9 +541,11 @@ __device__ __forceinline__ void main_issue(MainRegs<DH, CPW, PHASE> &M, const Cl
 
 // head of step hs = s - 1 on the LayerNorm'ed output of the last layer (xs): output_fc -> [fusion/hist_map] -> decoder/MLP ->
 // position feedback; leaves the next token in tok (autoregressive) and pred_st / h_out in global memory (workgroup g == 0).
+// out_only: stop behind output_fc (ha holds its result; the pipeline's head workgroups run the chain on one wave: head_chain_wave)
 template <int CPW>
 __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na, const float *xs, int ldx, float *red, float *ha,
-                                          float *hb, float *tok, const KsW<4, CPW> &wo, KsW<4, 1> sm_cur, float *pos = nullptr) {
+                                          float *hb, float *tok, const KsW<4, CPW> &wo, KsW<4, 1> sm_cur, float *pos = nullptr,
+                                          bool out_only = false) {
   // head of step hs = s - 1: output_fc -> [fusion/hist_map] -> decoder/MLP -> position feedback (mgcvae.py:435-446)
   const int hs = a.s - 1, tid = thread_idx(), K16 = a.d >> 4;
   __syncthreads();
@@ -563,7 +565,7 @@ __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na
     }
   });
   __syncthreads();
-  if (!a.tgt) {
+  if (!a.tgt && !out_only) {
     float *cur = ha, *alt = hb;
 #pragma unroll
     for (int i = 0; i < CHAIN_MAX; ++i) {
@@ -599,6 +601,120 @@ __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na
       if (pos) pos[r * 16 + c] = np;
       if (g == 0) a.pred_st[((size_t)(a0 + r) * a.ph + hs) * a.n_in + c] = np;
     }
+  }
+}
+
+// ---- the head's chain of small linears (decoder/MLP: Linear + LayerNorm + ReLU, Linear) for the 4 rows of a cluster on ONE wave.
+// head_step runs it on the matrix cores with two or three workgroup barriers per linear (K-split partial tiles through LDS,
+// LayerNorm on a wave per row): ~4 us of barriers and LDS round trips on every step of the decode's critical path.  Here lane
+// (row r = lane / 16, c = lane % 16) owns output columns c and c + 16 and nothing leaves the wave.  Same sums in the same order:
+// v_mfma_f32_16x16x4_f32 adds its four products as a forward chain of fused multiply-adds (tools/probe/mfma16_order.hip), a
+// 16-wide K chunk is four such steps (k = 4q + e, e outer), ks_reduce adds the chunks in order to 0, and layer_norm_rows'
+// 64-lane xor butterfly pairs (c, c ^ 16) first and then c ^ 8, 4, 2, 1 - which row rotations by 8, 4, 2, 1 reproduce once the
+// values have the matching period.  Taken when every linear of the chain has <= 32 inputs and outputs (chain_fits_wave).
+constexpr int CW_LD = 36;      // row stride of the staged weights W[col][k] (32 + 4: the 16 lanes of a row read different banks)
+__device__ __forceinline__ bool chain_fits_wave(const ClArgs &a) {
+  if (a.tgt || a.n_chain < 1 || a.n_in > 16) return false;
+  // (no a.chain[a.n_chain - 1]: an index known only at run time sends the whole argument block to scratch.  The last linear's
+  // width is n_in - mmt_decoder_forward refuses anything else - and a narrower one would only leave zeros in the missing columns.)
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < CHAIN_MAX; ++i)
+    if (i < a.n_chain) ok = ok && a.chain[i].k <= 32 && a.chain[i].n <= 32 && (!a.chain_ln[i].g || a.chain[i].n == 32);
+  return ok;
+}
+// packed [n/16][k/16][lane = 16q + j][e] = W[16s + j][16c + 4q + e]  ->  cw[i][col][k], zero beyond the padded matrix
+__device__ __forceinline__ void chain_stage(const ClArgs &a, float *cw) {
+#pragma unroll
+  for (int i = 0; i < CHAIN_MAX; ++i)
+    if (i < a.n_chain) {
+      const int kp = round16(a.chain[i].k), np = round16(a.chain[i].n), K16 = kp >> 4;
+      for (int idx = thread_idx(); idx < 32 * 32; idx += CNT) {
+        const int col = idx >> 5, k = idx & 31;
+        float v = 0.f;
+        if (col < np && k < kp) v = a.chain[i].w[((size_t)((col >> 4) * K16 + (k >> 4)) * 64 + 16 * ((k & 15) >> 2) + (col & 15)) * 4 + (k & 3)];
+        cw[(i * 32 + col) * CW_LD + k] = v;
+      }
+    }
+}
+template <int N>
+__device__ __forceinline__ float row_ror_add(float t) {      // t + (t of lane (l + N) % 16 of the same row)
+  return t + dpp_mov<0x120 + N>(t);
+}
+// the 64-lane butterfly of layer_norm_rows over a row of 32 values held two per lane (x0 = column c, x1 = column c + 16)
+__device__ __forceinline__ float row32_total(float x0, float x1) {
+  float t = (x0 + 0.f) + (x1 + 0.f);        // step 32 meets the idle lanes' zeros, step 16 the other half of the row
+  t = row_ror_add<8>(t);
+  t = row_ror_add<4>(t);
+  t = row_ror_add<2>(t);
+  t = row_ror_add<1>(t);
+  return t;
+}
+__device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na, float *ha, float *hb, float *tok, float *pos,
+                                                const float *cw) {
+#pragma clang fp contract(off)
+  const int hs = a.s - 1, lane = lane_id(), r = lane >> 4, c = lane & 15;
+  float *cur = ha, *alt = hb;
+  float out[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < CHAIN_MAX; ++i) {
+    if (i < a.n_chain) {
+      const int k16 = round16(a.chain[i].k) >> 4, n = a.chain[i].n;
+      const float *bias = a.chain[i].b;
+      f32x4 hv[2][4];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[ch][q] = *reinterpret_cast<const f32x4 *>(cur + r * LDO + 16 * ch + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int col = c + 16 * t;
+        const float *wrow = cw + (i * 32 + col) * CW_LD;
+        float sum = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          f32x4 wv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4 *>(wrow + 16 * ch + 4 * q);
+          float acc = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = fmaf(hv[ch][q][e], wv[q][e], acc);
+          sum = ch < k16 ? sum + acc : sum;
+        }
+        out[t] = col < n ? sum + (bias ? bias[col] : 0.f) : 0.f;
+      }
+      if (a.chain_ln[i].g) {      // n == 32: LayerNorm + ReLU of the row (layer_norm_rows<true>)
+        const float mu = row32_total(out[0], out[1]) * (1.0f / 32.0f);
+        const float d0 = out[0] - mu, d1 = out[1] - mu;
+        const float var = row32_total(d0 * d0, d1 * d1) * (1.0f / 32.0f);
+        const float rstd = 1.0f / sqrtf(var + MMT_LN_EPS);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float y = fmaf((out[t] - mu) * rstd, a.chain_ln[i].g[c + 16 * t], a.chain_ln[i].b[c + 16 * t]);
+          out[t] = fmaxf(y, 0.f);
+        }
+      }
+      alt[r * LDO + c] = out[0];
+      alt[r * LDO + c + 16] = out[1];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // written and read by this wave only
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float *t_ = cur;
+      cur = alt;
+      alt = t_;
+    }
+  }
+  // out[0] of lane (r, c < n_in) = delta of row r, column c: position feedback (head_step's last loop)
+  if (r < na && c < a.n_in) {
+    const float prev = hs == 0 ? a.start_pos[(size_t)(a0 + r) * a.n_in + c]
+                       : pos   ? pos[r * 16 + c]
+                               : a.pred_st[((size_t)(a0 + r) * a.ph + hs - 1) * a.n_in + c];
+    const float np = prev + out[0];
+    tok[r * LDTOK + c] = np;
+    if (pos) pos[r * 16 + c] = np;
+    a.pred_st[((size_t)(a0 + r) * a.ph + hs) * a.n_in + c] = np;
   }
 }
 
@@ -1989,6 +2105,9 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         stage(a.chain_ln[i].b, a.chain[i].n);
       }
   }
+  const bool wave_chain = chain_fits_wave(a);      // (a.chain[] biases / LayerNorm vectors already point into LDS)
+  float *cw = S.Ks;                                // the head workgroups stage no K/V rows: the chain's weights live there
+  if (wave_chain) chain_stage(a, cw);
   // once: the head's tiles and the token tile hold finite values (their padding columns must stay zero: nothing else writes
   // them) and rows 4..15 of the head's input tile are zero (a visit writes rows 0..3 only)
   for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) S.ha[i] = 0.f;
@@ -2040,7 +2159,11 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
       __syncthreads();
       if (*ps.abort) return;
       if (red_wave) reduce4_finish<AUX_SC1, DROP>(R, a, m, S.xs, ldx, false, false, DROP ? &k_red : nullptr);
-      if (s > 0) head_step<CPW>(a, 0, a0, na, S.xs, ldx, S.red, S.ha, S.hb, S.tok, wo, sm0, li < PIPE_MAXPOS ? S.pos + li * 64 : nullptr);
+      if (s > 0) {
+        float *posl = li < PIPE_MAXPOS ? S.pos + li * 64 : nullptr;
+        head_step<CPW>(a, 0, a0, na, S.xs, ldx, S.red, S.ha, S.hb, S.tok, wo, sm0, posl, wave_chain);
+        if (wave_chain && wave_id() == 0) head_chain_wave(a, a0, na, S.ha, S.hb, S.tok, posl, cw);
+      }
       if (a.tgt || s == 0)
         for (int i = tid; i < na * a.n_in; i += CNT) {
           const int r = i / a.n_in, c = i - r * a.n_in;
