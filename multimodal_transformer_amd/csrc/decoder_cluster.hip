@@ -611,8 +611,12 @@ __device__ __forceinline__ void head_step(const ClArgs &a, int g, int a0, int na
 // v_mfma_f32_16x16x4_f32 adds its four products as a forward chain of fused multiply-adds (tools/probe/mfma16_order.hip), a
 // 16-wide K chunk is four such steps (k = 4q + e, e outer), ks_reduce adds the chunks in order to 0, and layer_norm_rows'
 // 64-lane xor butterfly pairs (c, c ^ 16) first and then c ^ 8, 4, 2, 1 - which row rotations by 8, 4, 2, 1 reproduce once the
-// values have the matching period.  Taken when every linear of the chain has <= 32 inputs and outputs (chain_fits_wave).
-constexpr int CW_LD = 36;      // row stride of the staged weights W[col][k] (32 + 4: the 16 lanes of a row read different banks)
+// values have the matching period.  Taken when every linear of the chain has <= CWK inputs and <= 32 outputs (chain_fits_wave).
+// CWK = 32: the Basic / lane configurations; CWK = 64 (an instantiation of its own, so that the code of the first stays as it
+// was measured): the map configurations, whose fusion/hist_map takes output_fc's 32 values + the map feature's 32.
+template <int CWK>
+constexpr int CW_LD = CWK + 4;      // row stride of the staged weights W[col][k] (+ 4: the 16 lanes of a row read different banks)
+template <int CWK>
 __device__ __forceinline__ bool chain_fits_wave(const ClArgs &a) {
   if (a.tgt || a.n_chain < 1 || a.n_in > 16) return false;
   // (no a.chain[a.n_chain - 1]: an index known only at run time sends the whole argument block to scratch.  The last linear's
@@ -620,20 +624,21 @@ __device__ __forceinline__ bool chain_fits_wave(const ClArgs &a) {
   bool ok = true;
 #pragma unroll
   for (int i = 0; i < CHAIN_MAX; ++i)
-    if (i < a.n_chain) ok = ok && a.chain[i].k <= 32 && a.chain[i].n <= 32 && (!a.chain_ln[i].g || a.chain[i].n == 32);
+    if (i < a.n_chain) ok = ok && a.chain[i].k <= CWK && a.chain[i].n <= 32 && (!a.chain_ln[i].g || a.chain[i].n == 32);
   return ok;
 }
 // packed [n/16][k/16][lane = 16q + j][e] = W[16s + j][16c + 4q + e]  ->  cw[i][col][k], zero beyond the padded matrix
+template <int CWK>
 __device__ __forceinline__ void chain_stage(const ClArgs &a, float *cw) {
 #pragma unroll
   for (int i = 0; i < CHAIN_MAX; ++i)
     if (i < a.n_chain) {
       const int kp = round16(a.chain[i].k), np = round16(a.chain[i].n), K16 = kp >> 4;
-      for (int idx = thread_idx(); idx < 32 * 32; idx += CNT) {
-        const int col = idx >> 5, k = idx & 31;
+      for (int idx = thread_idx(); idx < 32 * CWK; idx += CNT) {
+        const int col = idx / CWK, k = idx % CWK;
         float v = 0.f;
         if (col < np && k < kp) v = a.chain[i].w[((size_t)((col >> 4) * K16 + (k >> 4)) * 64 + 16 * ((k & 15) >> 2) + (col & 15)) * 4 + (k & 3)];
-        cw[(i * 32 + col) * CW_LD + k] = v;
+        cw[(i * 32 + col) * CW_LD<CWK> + k] = v;
       }
     }
 }
@@ -650,6 +655,7 @@ __device__ __forceinline__ float row32_total(float x0, float x1) {
   t = row_ror_add<1>(t);
   return t;
 }
+template <int CWK>
 __device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na, float *ha, float *hb, float *tok, float *pos,
                                                 const float *cw) {
 #pragma clang fp contract(off)
@@ -661,29 +667,54 @@ __device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na,
     if (i < a.n_chain) {
       const int k16 = round16(a.chain[i].k) >> 4, n = a.chain[i].n;
       const float *bias = a.chain[i].b;
-      f32x4 hv[2][4];
+      if (CWK == 32 || k16 <= 2) {      // (always, or wave-uniform) both chunks' reads issued up front
+        f32x4 hv[2][4];
 #pragma unroll
-      for (int ch = 0; ch < 2; ++ch)
+        for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hv[ch][q] = *reinterpret_cast<const f32x4 *>(cur + r * LDO + 16 * ch + 4 * q);
+          for (int q = 0; q < 4; ++q) hv[ch][q] = *reinterpret_cast<const f32x4 *>(cur + r * LDO + 16 * ch + 4 * q);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int col = c + 16 * t;
-        const float *wrow = cw + (i * 32 + col) * CW_LD;
-        float sum = 0.f;
+        for (int t = 0; t < 2; ++t) {
+          const int col = c + 16 * t;
+          const float *wrow = cw + (i * 32 + col) * CW_LD<CWK>;
+          float sum = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-          f32x4 wv[4];
+          for (int ch = 0; ch < 2; ++ch) {
+            f32x4 wv[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4 *>(wrow + 16 * ch + 4 * q);
-          float acc = 0.f;
+            for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4 *>(wrow + 16 * ch + 4 * q);
+            float acc = 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = fmaf(hv[ch][q][e], wv[q][e], acc);
-          sum = ch < k16 ? sum + acc : sum;
+              for (int q = 0; q < 4; ++q) acc = fmaf(hv[ch][q][e], wv[q][e], acc);
+            sum = ch < k16 ? sum + acc : sum;
+          }
+          out[t] = col < n ? sum + (bias ? bias[col] : 0.f) : 0.f;
         }
-        out[t] = col < n ? sum + (bias ? bias[col] : 0.f) : 0.f;
+      } else {      // chunk by chunk in a loop (32 operand registers at a time: four chunks unrolled need 254 VGPRs)
+        float sum[2] = {0.f, 0.f};
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < k16; ++ch) {
+          f32x4 hv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const f32x4 *>(cur + r * LDO + 16 * ch + 4 * q);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float *wrow = cw + (i * 32 + c + 16 * t) * CW_LD<CWK> + 16 * ch;
+            f32x4 wv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const f32x4 *>(wrow + 4 * q);
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc = fmaf(hv[q][e], wv[q][e], acc);
+            sum[t] = sum[t] + acc;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) out[t] = (c + 16 * t) < n ? sum[t] + (bias ? bias[c + 16 * t] : 0.f) : 0.f;
       }
       if (a.chain_ln[i].g) {      // n == 32: LayerNorm + ReLU of the row (layer_norm_rows<true>)
         const float mu = row32_total(out[0], out[1]) * (1.0f / 32.0f);
@@ -2073,7 +2104,7 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
 
 // The head workgroups: head of the previous step (s > 0) and embedding of the next token, for the clusters
 // replica + R * (j + NHW * i), i = 0, 1, ...  The token rows go to x0buf (tag s & 1), a buffer of their own.
-template <int CPW, bool DROP = false>
+template <int CPW, bool DROP = false, int CWK = 32>
 __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j, const PipeLds &S, const PipeSync &ps) {
   ClArgs a = f.a;
   const int d = a.d, ldx = d + MMT_PAD, K16 = d >> 4, tid = thread_idx();
@@ -2105,9 +2136,10 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         stage(a.chain_ln[i].b, a.chain[i].n);
       }
   }
-  const bool wave_chain = chain_fits_wave(a);      // (a.chain[] biases / LayerNorm vectors already point into LDS)
+  const bool wave_chain = chain_fits_wave<CWK>(a);      // (a.chain[] biases / LayerNorm vectors already point into LDS)
   float *cw = S.Ks;                                // the head workgroups stage no K/V rows: the chain's weights live there
-  if (wave_chain) chain_stage(a, cw);
+  static_assert(CHAIN_MAX * 32 * CW_LD<CWK> <= 2 * (2 * 4 * KMAX * (32 + 4)), "the staged chain must fit the K/V staging tiles (Ks + Vs)");
+  if (wave_chain) chain_stage<CWK>(a, cw);
   // once: the head's tiles and the token tile hold finite values (their padding columns must stay zero: nothing else writes
   // them) and rows 4..15 of the head's input tile are zero (a visit writes rows 0..3 only)
   for (int i = tid; i < 2 * 16 * LDO + 16 * LDTOK; i += CNT) S.ha[i] = 0.f;
@@ -2162,7 +2194,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
       if (s > 0) {
         float *posl = li < PIPE_MAXPOS ? S.pos + li * 64 : nullptr;
         head_step<CPW>(a, 0, a0, na, S.xs, ldx, S.red, S.ha, S.hb, S.tok, wo, sm0, posl, wave_chain);
-        if (wave_chain && wave_id() == 0) head_chain_wave(a, a0, na, S.ha, S.hb, S.tok, posl, cw);
+        if (wave_chain && wave_id() == 0) head_chain_wave<CWK>(a, a0, na, S.ha, S.hb, S.tok, posl, cw);
       }
       if (a.tgt || s == 0)
         for (int i = tid; i < na * a.n_in; i += CNT) {
@@ -2183,7 +2215,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
   }
 }
 
-template <int DH, int CPW, int D, int FS, bool DROP = false>
+template <int DH, int CPW, int D, int FS, bool DROP = false, int CWK = 32>
 __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
   extern __shared__ __align__(16) float smem[];
   const PipeLds S = pipe_lds<DH>(smem, f.a.d);
@@ -2200,7 +2232,7 @@ __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
     else if (q < H + H / 2) pipe_stage<DH, PH_B, 2, D, FS, DROP>(f, layer, 2 * (q - H), replica, S, ps);
     else pipe_stage<DH, PH_C, 1, D, FS, DROP>(f, layer, q - H - H / 2, replica, S, ps);
   } else {
-    pipe_head<CPW, DROP>(f, replica, rb - f.nlayers * per_layer, S, ps);
+    pipe_head<CPW, DROP, CWK>(f, replica, rb - f.nlayers * per_layer, S, ps);
   }
 }
 
@@ -2326,6 +2358,20 @@ int dev_ncu(int dev) {
 // workgroup takes in its weight slice at ~50 GB/s, and the partials it sums scale with the rows).
 bool mfma4_fits(const mmt_decoder *dec);
 enum { ONE_LAUNCH_NONE = 0, ONE_LAUNCH_FUSED = 1, ONE_LAUNCH_PIPE = 2 };
+// A linear of the head's chain (fusion/hist_map, decoder/MLP) with 33..64 inputs and none wider: the pipeline instantiation whose
+// one-wave head chain stages 64 inputs (CWK = 64) - the map configurations.  Otherwise the CWK = 32 instantiation (which runs
+// wider chains on the matrix cores, as the other forms do).
+static bool pipe_wide_chain(const mmt_decoder *dec, bool teacher_forced) {
+  if (teacher_forced) return false;
+  int kmax = 0, nmax = 0;
+  auto scan = [&](const mmt_mlp &M) {
+    for (int i = 0; i < M.n_hidden; ++i) kmax = std::max(kmax, (int)M.hidden[i].k), nmax = std::max(nmax, (int)M.hidden[i].n);
+    kmax = std::max(kmax, (int)M.out.k), nmax = std::max(nmax, (int)M.out.n);
+  };
+  if (dec->has_map_fusion) scan(dec->map_fusion);
+  scan(dec->head);
+  return kmax > 32 && kmax <= 64 && nmax <= 32;
+}
 struct PipeGeom {
   int R, NHW, grid;     // replicas of the pipeline, head workgroups per replica, workgroups in all
   float *x0buf;
@@ -2544,6 +2590,10 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
         (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
       }
     }
     ds.attr_mask.fetch_or(fam_bit, std::memory_order_release);
@@ -2619,8 +2669,12 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         f.NC = NC;
         if (drop) f.drop = *drop;
         if constexpr (DH == 32 && CPW == 2) {    // the pipeline is built for the shipped geometry (pipe_geom_ok): d = 256, d_ff / H = 64
-          if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true>), dim3(pg.grid), blk, pipe_lds_floats<32>(256) * sizeof(float), st, f);
-          else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64>), dim3(pg.grid), blk, pipe_lds_floats<32>(256) * sizeof(float), st, f);
+          const size_t plds = pipe_lds_floats<32>(256) * sizeof(float);
+          if (pipe_wide_chain(dec, a.tgt != nullptr)) {      // a head linear with 33..64 inputs (fusion/hist_map): the instantiation that stages them
+            if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>), dim3(pg.grid), blk, plds, st, f);
+            else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>), dim3(pg.grid), blk, plds, st, f);
+          } else if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true>), dim3(pg.grid), blk, plds, st, f);
+          else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64>), dim3(pg.grid), blk, plds, st, f);
         }
         p = 3 * L * ph;
       } else {
@@ -2692,7 +2746,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 }
 
 // The one-launch kernel spins on its siblings: it is only started when the occupancy query says the whole grid is resident.
-static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool drop = false) {
+static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool drop = false, bool wide = false) {
   constexpr int DH = 32;
   constexpr int LD1 = 3 * DH + 8;
   const size_t lds = pipe ? pipe_lds_floats<DH>(d) * sizeof(float)
@@ -2700,7 +2754,9 @@ static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool
                              (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
   int per_cu = 0;
   hipError_t e;
-  if (pipe && drop) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, CNT, lds);
+  if (pipe && wide) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>, CNT, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>, CNT, lds);
+  else if (pipe && drop) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, CNT, lds);
   else if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64>, CNT, lds);
   else e = cpw2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 2>, CNT, lds)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_fused4_kernel<32, 1>, CNT, lds);
@@ -2785,7 +2841,7 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   PipeGeom pg = {0, 0, 0, nullptr};
   if (allow_fused != 0 && m4 && !dec_env().no_fused && !g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) {
     if (d == 256 && dec->d_ff == 64 * H) pg = pipe_geom(L, H, NC, ncu);      // the geometry the pipeline kernel is compiled for
-    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d, drop != nullptr)) one_launch = ONE_LAUNCH_PIPE;
+    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d, drop != nullptr, pipe_wide_chain(dec, tgt != nullptr))) one_launch = ONE_LAUNCH_PIPE;
     else if (allow_fused != 2 && NC * H <= ncu && one_launch_fits(false, d > 128, NC * H, ncu, d)) one_launch = ONE_LAUNCH_FUSED;
   }
   const bool fuse_phases = one_launch != ONE_LAUNCH_NONE;
