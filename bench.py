@@ -267,21 +267,26 @@ def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, grou
     elapsed, loss = timed(group, step, steps, 0)
     assert torch.isfinite(loss).all()
     n_par = sum(p.numel() for _, p in tr.engine.named_params)
+    ar_ms, overlap = tr.allreduce_ms(), tr.overlap
+    drop_info = None
+    if dropout:
+        drop_info = {"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
+                     "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
+                     "decode": (f"mmt_decoder_forward_dropout: {_last_decoder_path()}, reading the step's keep masks"
+                                if tr.engine._ar_decode_takes_masks() else
+                                "step by step on the stash kernels (tokens depend on the masks)")}
+    tr.close()      # ordered teardown (graphs, events, the last Work) before anybody destroys the process group
     return {"metric": "train steps/sec (fwd+bwd+clip+AdamW)", "value": steps / elapsed, "unit": "steps/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "per_gpu_batch": B,
             "global_batch": B * world, "agents_per_s": B * world * steps / elapsed,
-            "allreduce_ms": tr.allreduce_ms(), "allreduce_bytes": 4 * n_par if world > 1 else 0,
+            "allreduce_ms": ar_ms, "allreduce_bytes": 4 * n_par if world > 1 else 0,
             "allreduce_form": ("two buckets: the decoder-side gradients reduced asynchronously beside the history encoder's backward "
                                "graph, the rest behind it; allreduce_ms = what the all-reduce adds between backward and optimizer "
                                "(HIP events: first bucket issued -> last bucket reduced, minus that backward graph)")
-                              if tr.overlap else ("one bucket behind the backward" if world > 1 else None),
+                              if overlap else ("one bucket behind the backward" if world > 1 else None),
             "parallelism": f"dp{world}, flat fp32 gradient of {n_par} elements all-reduced per step (RCCL) in two buckets, parameters "
                            f"broadcast from rank 0 at start" if world > 1 else "single GPU",
-            "dropout": ({"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
-                         "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
-                         "decode": (f"mmt_decoder_forward_dropout: {_last_decoder_path()}, reading the step's keep masks"
-                                    if tr.engine._ar_decode_takes_masks() else
-                                    "step by step on the stash kernels (tokens depend on the masks)")} if dropout else 0.0),
+            "dropout": drop_info if dropout else 0.0,
             "last_loss_rank0": float(loss),
             "algorithmic_tflops": 3 * (MFLOP_ENCODER + MFLOP_DECODER + MFLOP_HEAD) * 1e6 * B * world * steps / elapsed / 1e12}
 
@@ -298,8 +303,30 @@ def predict_fn(model, mode, dev, B, history, ph, seed):
     return (lambda: model.predict(x, x_st, lanes, None, maps, ph)), (x, x_st, lanes, maps), batch
 
 
-def config_report(mode, B, dev, history, ph, steps, group):
-    """One of BASELINE configs 3-5 on this GPU: whole-predict throughput + per-kernel times and rooflines."""
+def sync_predict_ms(model, mode, dev, B, history, ph, iters=100):
+    """A SYNCHRONOUS caller (evaluate.py copies every prediction to the host, trajectron.py:216-221): wall time per predict +
+    ``.cpu()``, eager and replayed from the captured HIP graph (``MultimodalGenerativeCVAE.predict_graphed``)."""
+    fn, _, _ = predict_fn(model, mode, dev, B, history, ph, seed=9)
+    pick = (lambda o: o[1]) if mode == "lane_cnn" else (lambda o: o[0])
+    out = {}
+    for name, graphed in (("eager", False), ("graph", True)):
+        model.graph_predict = graphed
+        try:
+            for _ in range(5):
+                pick(fn()).cpu()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                pick(fn()).cpu()
+            out[name] = (time.perf_counter() - t0) / iters * 1e3
+        finally:
+            model.graph_predict = False
+    return out
+
+
+def config_report(mode, B, dev, history, ph, steps, group, train_steps=0):
+    """One of BASELINE configs 3-5 on this GPU: whole-predict throughput + per-kernel times and rooflines (+ its training step:
+    the 8-GPU run's single-GPU denominator, VERDICT r2 #8)."""
     hp, model, reg = build_model(mode, dev, history, ph)
     fn, tensors, _ = predict_fn(model, mode, dev, B, history, ph, seed=5)
     elapsed, out = timed(group, fn, steps, 3)
@@ -314,6 +341,13 @@ def config_report(mode, B, dev, history, ph, steps, group):
         rep["parity"] = "unpinned (vit_pytorch==0.33.2 is neither in the reference tree nor installable offline; checked against the CPU restatement only)"
     if mode == "lane_cnn":
         rep["note"] = "the reference decodes all three lanes with lane 0's feature (mgcvae.py:404): one decode, returned three times"
+    if train_steps:
+        try:
+            t = bench_train(model, hp, dev, B, history, ph, 0, 1, train_steps, 3, group, with_map=(mode in ("map_cnn", "map_vit")),
+                            with_lanes=(mode == "lane_cnn"))
+            rep["train"] = {k: t[k] for k in ("value", "unit", "ms_per_step", "steps", "per_gpu_batch", "last_loss_rank0")}
+        except Exception as e:
+            rep["train"] = {"error": f"{type(e).__name__}: {e}"}
     return rep
 
 
@@ -442,6 +476,19 @@ def main():
                                                             "last_loss_rank0")}
             except Exception as e:
                 train["with_dropout"] = {"error": f"{type(e).__name__}: {e}"}
+    train_big = None
+    if not args.no_train and not distributed and args.mode == "basic" and B == 128:
+        # BASELINE config 2's GLOBAL batch (1024 = 8 x 128) on ONE GPU: the denominator of the 8-GPU data-parallel run
+        train_big = {}
+        for key, drop in (("dropout_free", False), ("with_dropout", True)):
+            try:
+                _, bmodel, _ = build_model(args.mode, dev, args.history, ph)
+                t = bench_train(bmodel, dict(hp), dev, 1024, args.history, ph, 0, 1, 8, 2, group, dropout=drop)
+                train_big[key] = {k: t[k] for k in ("value", "unit", "ms_per_step", "steps", "per_gpu_batch", "agents_per_s",
+                                                    "algorithmic_tflops", "last_loss_rank0")}
+                del bmodel
+            except Exception as e:
+                train_big[key] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         x, x_st, lanes, maps = tensors
@@ -491,27 +538,45 @@ def main():
             for name, mode, bb in (("map_cnn_b128", "map_cnn", 128), ("map_vit_b128", "map_vit", 128),
                                    ("lane_cnn_b128", "lane_cnn", 128), ("lane_cnn_b1024", "lane_cnn", 1024)):
                 try:
-                    cfgs[name] = config_report(mode, bb, dev, args.history, ph, 20, group)
+                    cfgs[name] = config_report(mode, bb, dev, args.history, ph, 20, group,
+                                               train_steps=(10 if bb == 128 and mode != "map_vit" and not args.no_train else 0))
                 except Exception as e:
                     cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
             line["configs"] = cfgs
         line["train"] = train
+        line["train_b1024"] = train_big
+        if not distributed:
+            try:
+                sp = sync_predict_ms(model, args.mode, dev, B, args.history, ph)
+                line["sync_ms_per_step"] = sp["graph"]
+                line["sync_ms_per_step_eager"] = sp["eager"]
+                line["sync_note"] = ("wall time of predict + .cpu() per call, one after the other (the caller evaluate.py is): "
+                                     "'sync_ms_per_step' replays the predict from a HIP graph captured per shape "
+                                     "(model.graph_predict = True), '_eager' issues the launches from Python every call")
+            except Exception as e:
+                line["sync_ms_per_step"] = None
+                line["sync_note"] = f"{type(e).__name__}: {e}"
         if not args.no_cpu_baseline and not distributed:
             line["cpu_baseline"] = cpu_baseline(args.mode, hp, batch, ph)
             if train is not None and "error" not in train:
                 train["cpu_baseline"] = cpu_train_baseline(hp, batch, ph)
         else:
             line["cpu_baseline"] = None
+        line["teardown"] = ("ordered: every Trainer closed (graphs, events, last Work dropped after a device synchronise), barrier, "
+                            "synchronise, destroy_process_group, normal interpreter exit - this line is printed first, the "
+                            "process's exit code is the teardown's verdict") if dist is not None else "no process group"
         print(json.dumps(line), flush=True)
     if dist is not None:
-        # every rank has finished its collectives; leave without tearing the RCCL communicator down: that teardown has been seen
-        # to abort() a process (one-rank rehearsal under pytest, once in a handful of runs), which would turn a finished
-        # measurement into a failed launch
+        # Ordered teardown, exit code from the real exit path (round 2 left through os._exit here).  Every Trainer
+        # was closed by bench_train; nothing of this process is in flight on the communicator any more.
+        import gc
+        del model, reg, step, tensors
+        gc.collect()
         dist.barrier()
         torch.cuda.synchronize()
+        dist.destroy_process_group()
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
 
 
 if __name__ == "__main__":

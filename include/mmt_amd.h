@@ -312,7 +312,11 @@ int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8
  * array of MMT_DECODER_STATIC_SCRATCH_FLOATS floats (44 MiB per GPU the library runs on, held until the process ends); sizes
  * whose mmt_decoder_workspace_floats() exceeds it are rejected with MMT_EINVAL.  Calls no hipMalloc / hipFree.  Every call on
  * a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race - serialise them.  Results are
- * bit-identical to mmt_decoder_forward. */
+ * bit-identical to mmt_decoder_forward.
+ * Under HIP-graph capture: the FIRST call on a device (and the first call of each decoder form / shape class on it) makes
+ * runtime queries that are not stream operations (hipGetSymbolAddress, hipFuncSetAttribute, the occupancy query) and must
+ * therefore happen OUTSIDE a capture - call it once eagerly with the shapes that will be captured, then capture; later calls
+ * only enqueue kernels and a memset on `stream` (tests/test_zz_no_alloc.py captures and replays one). */
 #define MMT_DECODER_STATIC_SCRATCH_FLOATS (11u << 20)
 int mmt_decoder_forward_static(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
                                const float *start_pos, const float *map_feat, int map_dim,

@@ -221,14 +221,23 @@ def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
 
 
 # ---- group launches: many independent jobs of one kind in ONE launch ------------------------------------------------
-_GROUP_TABLES = {}       # host table bytes -> (device copy, njobs, nblocks); the jobs' pointers are part of the key
+# host table bytes -> (device copy, njobs, nblocks); the jobs' pointers are part of the key.  A launch bakes the device table's
+# address into whatever HIP graph is capturing, so a table must live as long as every graph that replays it: an owner that
+# captures (TrainEngine) passes its OWN dict as ``cache`` and keeps it next to its graphs -- entries of such a dict are never
+# evicted, they die with the owner.  The module-level dict serves ad-hoc eager calls only (tests, tools) and is bounded.
+_GROUP_TABLES = {}
+_GROUP_TABLES_MAX = 64
 
 
-def _group_launch(kind, jobs, plan, run, what):
+def _group_launch(kind, jobs, plan, run, what, cache=None):
     """jobs: ctypes array of job structs.  The launch table is planned on the host and uploaded once per distinct job list
-    (a later call with the same pointers and shapes -- every replay of a captured step -- finds it by its bytes)."""
+    (a later call with the same pointers and shapes -- every replay of a captured step -- finds it by its bytes).  Returns the
+    device table (the caller may hold it)."""
+    shared = cache is None
+    if shared:
+        cache = _GROUP_TABLES
     key = (kind, bytes(jobs))
-    hit = _GROUP_TABLES.get(key)
+    hit = cache.get(key)
     lib = _lib.load()
     if hit is None:
         if torch.cuda.is_current_stream_capturing():
@@ -237,28 +246,37 @@ def _group_launch(kind, jobs, plan, run, what):
         _lib.check(plan(jobs, len(jobs), None, 0, C.byref(nbytes), C.byref(nblocks)), what + "_plan")
         host = (C.c_uint8 * nbytes.value)()
         _lib.check(plan(jobs, len(jobs), host, nbytes.value, C.byref(nbytes), C.byref(nblocks)), what + "_plan")
-        table = torch.frombuffer(host, dtype=torch.uint8).clone().to(torch.cuda.current_device())
-        if len(_GROUP_TABLES) >= 64:       # engines come and go in a test session: keep the cache bounded
-            _GROUP_TABLES.pop(next(iter(_GROUP_TABLES)))
-        hit = _GROUP_TABLES[key] = (table, len(jobs), nblocks.value)
+        table = torch.frombuffer(host, dtype=torch.uint8).clone().to(_group_device())
+        if shared and len(cache) >= _GROUP_TABLES_MAX:       # ad-hoc callers come and go in a test session: keep this one bounded
+            cache.pop(next(iter(cache)))
+        hit = cache[key] = (table, len(jobs), nblocks.value)
+    elif shared and torch.cuda.is_current_stream_capturing():
+        # a graph is about to reference a table that only the bounded, shared cache keeps alive
+        raise MmtError(f"{what}: group launches under graph capture need an owner's table cache (cache=...)")
     table, njobs, nblocks = hit
     _lib.check(run(C.c_void_p(table.data_ptr()), njobs, nblocks, _stream()), what)
+    return table
 
 
-def gemm_group(calls):
+def _group_device():
+    return torch.cuda.current_device()
+
+
+def gemm_group(calls, cache=None):
     """``calls``: list of keyword dicts, each the arguments of a split-K / asum ``gemm`` (the deferred weight gradients of a
-    step).  One launch runs the tiles of all of them; results are those of the separate calls, bit for bit."""
+    step).  One launch runs the tiles of all of them; results are those of the separate calls, bit for bit.  ``cache``: the
+    owner's table dict (see ``_GROUP_TABLES``); required when the launch is captured into a graph."""
     if not calls:
-        return
+        return None
     lib = _lib.load()
     jobs = (_lib.GemmArgs * len(calls))(*[_gemm_args(**kw) for kw in calls])
-    _group_launch("gemm", jobs, lib.mmt_gemm_group_plan, lib.mmt_gemm_group, "mmt_gemm_group")
+    return _group_launch("gemm", jobs, lib.mmt_gemm_group_plan, lib.mmt_gemm_group, "mmt_gemm_group", cache)
 
 
-def ln_param_grads_group(calls):
-    """``calls``: list of keyword dicts, each the arguments of ``ln_param_grads``; one launch."""
+def ln_param_grads_group(calls, cache=None):
+    """``calls``: list of keyword dicts, each the arguments of ``ln_param_grads``; one launch.  ``cache`` as in ``gemm_group``."""
     if not calls:
-        return
+        return None
     lib = _lib.load()
     jobs = (_lib.LnGradJob * len(calls))()
     for J, kw in zip(jobs, calls):
@@ -273,7 +291,7 @@ def ln_param_grads_group(calls):
                 raise MmtError(f"ln_param_grads: {n} must be a contiguous vector of N elements")
         J.dy, J.xhat, J.gw, J.gb = dy.data_ptr(), xhat.data_ptr(), gw.data_ptr(), gb.data_ptr()
         J.ld, J.part_stride, J.M, J.N, J.splitk = ld, int(kw.get("part_stride", 0)), M, N, int(kw.get("splitk", 1))
-    _group_launch("ln", jobs, lib.mmt_ln_grad_group_plan, lib.mmt_ln_grad_group, "mmt_ln_grad_group")
+    return _group_launch("ln", jobs, lib.mmt_ln_grad_group_plan, lib.mmt_ln_grad_group, "mmt_ln_grad_group", cache)
 
 
 def _contig2(t, name, shape=None):

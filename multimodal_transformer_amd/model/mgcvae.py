@@ -141,22 +141,30 @@ class MultimodalGenerativeCVAE(object):
         return memory, None, pad, inputs_st[:, -1], inputs[:, -1, 0:2], encoded_lane, encoded_map
 
     def _train_mode_map_dropout(self, encoded_map):
-        """``F.dropout(encoded_map, cnn_param.dropout, training=(mode == TRAIN))`` (mgcvae.py:291-293) with this package's
-        counter-based masks.  (The encoder / ViT dropouts of training mode live in the training step, training.py: this
+        """``F.dropout(encoded_map, cnn_param.dropout, training=(mode == TRAIN))`` (mgcvae.py:291-293): gated on the MODE only,
+        like the reference -- ``F.dropout`` does not consult the module's train / eval flag -- with this package's
+        counter-based masks: Philox key = ``self.dropout_seed`` (default 0; an attribute the caller may set), mask stream
+        0xFFFF, counter advanced once per call; unrelated to a ``Trainer``'s seed.  The keep bytes are cached per (shape, device);
+        the output is a fresh tensor (the caller owns it).  (The encoder / ViT dropouts of training mode live in the training step, training.py: this
         function's kernels are the inference ones.)"""
         from .. import _train_kernels as K
         p = float(self.hyperparams["map_encoder"]["cnn_param"]["dropout"])
-        if p <= 0.0 or not self._m("map_encoder").training:
+        if p <= 0.0:
             return encoded_map
         dev = encoded_map.device
         rng = self.__dict__.get("_map_rng")
         if rng is None or rng.device != dev:
             rng = self.__dict__["_map_rng"] = torch.tensor([int(self.__dict__.get("dropout_seed", 0)), 0], dtype=torch.int64).to(dev)
         n = encoded_map.numel()
-        keep = torch.empty((n + 3) & ~3, dtype=torch.uint8, device=dev)
+        key = (tuple(encoded_map.shape), dev)
+        bufs = self.__dict__.setdefault("_map_drop_bufs", {})
+        if key not in bufs:
+            bufs.clear()            # (one shape at a time: the batch size of the caller's loop)
+            bufs[key] = torch.empty((n + 3) & ~3, dtype=torch.uint8, device=dev)
+        keep = bufs[key]
+        out = torch.empty_like(encoded_map, memory_format=torch.contiguous_format)
         K.dropout_mask(keep, p, rng, 0xFFFF)
         K.rng_advance(rng)
-        out = torch.empty_like(encoded_map, memory_format=torch.contiguous_format)
         K.dropout_apply(encoded_map.contiguous(), keep[:n], 1.0 / (1.0 - p), out)
         return out
 
@@ -251,7 +259,73 @@ class MultimodalGenerativeCVAE(object):
 
     # ------------------------------------------------------------------ public entry points
     def predict(self, inputs, inputs_st, inputs_lane, lane_t_mask, map, prediction_horizon):
-        """mgcvae.py:720-773 -> (history_pred (B,ph,2) metres | None, lane_pred (B,3,ph,2) metres | None/[])."""
+        """mgcvae.py:720-773 -> (history_pred (B,ph,2) metres | None, lane_pred (B,3,ph,2) metres | None/[]).
+        With ``self.graph_predict = True`` fixed shapes replay from a HIP graph (``predict_graphed``)."""
+        if self.__dict__.get("graph_predict", False) and inputs.is_cuda:
+            return self.predict_graphed(inputs, inputs_st, inputs_lane, lane_t_mask, map, prediction_horizon)
+        return self._predict(inputs, inputs_st, inputs_lane, lane_t_mask, map, prediction_horizon)
+
+    # ------------------------------------------------------------------ graph-replayed predict (fixed shapes)
+    GRAPH_CACHE_MAX = 8
+
+    def _graph_modules(self):
+        return [m for m in self.node_modules.values()]
+
+    def _graph_weights_sig(self, params):
+        """Cheap staleness check of a captured predict: the graph reads the packed weight copies at fixed addresses, which are
+        rebuilt when a parameter's version counter moves (nn_component._PackedMixin) or when a Trainer drops the caches after
+        writing the parameters through raw pointers."""
+        v = 0
+        for p_ in params:
+            v += p_._version
+        return v, tuple(id(m.__dict__.get("_pack_cache")) for m in self._graph_modules())
+
+    def reset_predict_graphs(self):
+        """Drop every captured predict (after replacing parameter OBJECTS, e.g. ``module.to`` / ``load_models``; in-place updates
+        are noticed by themselves)."""
+        self.__dict__.pop("_predict_graphs", None)
+
+    def predict_graphed(self, inputs, inputs_st, inputs_lane, lane_t_mask, map, prediction_horizon):
+        """``predict`` for serving loops of a fixed shape (evaluate.py's per-scene ``Trajectron.predict`` copies every result to
+        the host, trajectron.py:216-221, so the host time of a call is not hidden behind the GPU): the whole call -- history
+        encoder beside the map encoder on the side stream, cross-K/V, the one-launch decode, head, un-standardise -- is captured
+        ONCE per (mode, B, T, ph) into a HIP graph and replayed: the inputs are copied into the graph's static buffers, the
+        outputs are clones of its static outputs (fresh tensors, as ``predict`` returns).  The first call of a shape runs
+        eagerly (set-up that is not a stream operation: weight packing, workspaces, kernel attributes), the second captures.
+        ``mmt_decoder_status`` is NOT consulted here (it synchronises): callers that read results on the host wrap the call in
+        ``ops.checked`` like ``Trajectron.predict`` does; a re-issued call then runs eagerly on the launch-per-phase kernels,
+        and the captured graph of that shape is dropped."""
+        ph = int(prediction_horizon)
+        ts = (inputs, inputs_st, inputs_lane, map)
+        key = (ph,) + tuple(None if t is None else (tuple(t.shape), t.dtype) for t in ts)
+        cache = self.__dict__.setdefault("_predict_graphs", {})
+        ent = cache.get(key)
+        if ent is not None and ent["state"] == "ready":
+            if ent["sig"] != self._graph_weights_sig(ent["params"]) or ent["generation"] != ops.decoder_form_generation():
+                ent = None                                   # weights repacked / a one-launch form was disabled since: start over
+        if ent is None:
+            if len(cache) >= self.GRAPH_CACHE_MAX:
+                cache.pop(next(iter(cache)))
+            cache[key] = {"state": "warm"}
+            return self._predict(inputs, inputs_st, inputs_lane, lane_t_mask, map, ph)
+        if ent["state"] == "warm":
+            torch.cuda.synchronize(inputs.device)
+            static = [None if t is None else t.detach().clone().contiguous() for t in ts]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                outs = self._predict(static[0], static[1], static[2], lane_t_mask, static[3], ph)
+            params = [p_ for m in self._graph_modules() for p_ in m.parameters()]
+            ent.update(state="ready", graph=g, static=static, outs=outs, params=params, sig=self._graph_weights_sig(params),
+                       generation=ops.decoder_form_generation())
+        else:
+            for dst, src in zip(ent["static"], ts):
+                if dst is not None:
+                    dst.copy_(src, non_blocking=True)
+        ent["graph"].replay()
+        hist, lane = ent["outs"]
+        return (hist.clone() if torch.is_tensor(hist) else hist), (lane.clone() if torch.is_tensor(lane) else lane)
+
+    def _predict(self, inputs, inputs_st, inputs_lane, lane_t_mask, map, prediction_horizon):
         memory, _, pad, n0, node_pos, enc_lane, enc_map = self.obtain_encoded_tensors(
             ModeKeys.EVAL, inputs, inputs_st, inputs_lane, map)
         hist, lane = self.at_dec(memory, None, pad, n0, enc_lane, enc_map, prediction_horizon)

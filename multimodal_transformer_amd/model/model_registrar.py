@@ -121,8 +121,15 @@ class ModelRegistrar(nn.Module):
         install_reference_aliases()
         path = self._path(iter_num)
         allowed = _allowed_checkpoint_globals()
-        needed = torch.serialization.get_unsafe_globals_in_checkpoint(path)
-        extra = sorted(n for n in needed if n not in allowed)
+        from .._lib import MmtError
+        try:
+            needed = torch.serialization.get_unsafe_globals_in_checkpoint(path)
+        except Exception as e:      # e.g. a legacy (non-zip) torch.save file: the scan itself cannot read it
+            if not trusted:
+                raise MmtError(f"{path}: cannot list the objects this checkpoint references ({type(e).__name__}: {e}); "
+                               "pass trusted=True to unpickle it anyway (executes code from the file)") from e
+            needed = None
+        extra = sorted(n for n in needed if n not in allowed) if needed is not None else ["<unscanned>"]
         self.model_dict.clear()
         if not extra:
             with torch.serialization.safe_globals([(allowed[n], n) for n in needed]):
@@ -130,7 +137,6 @@ class ModelRegistrar(nn.Module):
         elif trusted:
             self.model_dict = torch.load(path, map_location=self.device, weights_only=False)
         else:
-            from .._lib import MmtError
             raise MmtError(f"{path} references objects a registrar checkpoint has no business holding: {extra}; "
                            "pass trusted=True to unpickle it anyway (executes code from the file)")
 

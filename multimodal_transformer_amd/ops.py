@@ -504,6 +504,7 @@ def decoder_select(impl: str = "auto"):
     if impl not in table:
         raise MmtError(f"decoder_select: unknown implementation {impl!r}")
     _lib.check(_lib.load().mmt_decoder_select(table[impl]), "mmt_decoder_select")
+    _bump_form_generation()
 
 
 DECODER_PATHS = {0: "none", 1: "mmt_decoder_kernel (persistent decoder, one launch)",
@@ -519,6 +520,19 @@ def decoder_last_path():
     return code, DECODER_PATHS.get(code, "?")
 
 
+_form_generation = [0]
+
+
+def _bump_form_generation():
+    _form_generation[0] += 1
+
+
+def decoder_form_generation():
+    """Moves whenever the kernel form behind decoder_forward / encoder_forward may have changed (decoder_select, a one-launch form
+    disabled after a time-out): a HIP graph captured under an older value bakes in a form that must not be replayed."""
+    return _form_generation[0]
+
+
 def decoder_status(stream=None):
     """Synchronise and raise MmtError if a one-launch decode on the current device timed out since the last check (its outputs
     are NaN; the library then keeps that form disabled on the device, so re-issuing the call succeeds)."""
@@ -526,6 +540,7 @@ def decoder_status(stream=None):
         _lib.check(_lib.load().mmt_decoder_status(_stream() if stream is None else stream), "mmt_decoder_status")
     except MmtError:
         _enc_ws_cache.clear()      # (a timed-out split encoder leaves its progress words inconsistent: fresh, zeroed buffers next time)
+        _bump_form_generation()
         raise
 
 

@@ -441,6 +441,7 @@ class TrainEngine:
         self.n_pos = self.dec.input_fc.weight.shape[1]
         self.n_out = self.dec.output_fc.weight.shape[0]
         self._pdec = None
+        self._group_cache = {}          # device launch tables of the group launches (K._group_launch), owned by this engine
         self.hp = hp
         self.use_dropout = bool(self.enc.training) if dropout is None else bool(dropout)
         self.drop = _DropPlan(self.device, seed)
@@ -883,8 +884,10 @@ class TrainEngine:
         if self._deferred is not None:
             gemms, lns = self._deferred
             self._deferred = None
-            K.gemm_group(gemms)
-            K.ln_param_grads_group(lns)
+            # the launch tables live in the engine's own cache: the Trainer's captured graphs hold their addresses, so they
+            # must not be evicted while this engine (and with it those graphs) is alive
+            K.gemm_group(gemms, cache=self._group_cache)
+            K.ln_param_grads_group(lns, cache=self._group_cache)
 
     def _sum_split_parts(self, lo=0, hi=None):
         if self._split_used:
@@ -1255,6 +1258,33 @@ class Trainer:
                 tot -= ev[2].elapsed_time(ev[3])
         return max(tot, 0.0) / len(self._ar_events)
 
+    def close(self):
+        """Ordered teardown, to be called before ``torch.distributed.destroy_process_group()``: wait for everything
+        this trainer enqueued -- the graph replays on the current stream AND the collectives on the process group's own stream,
+        which ``work.wait()`` only orders the current stream behind --, then drop what references device or communicator state in
+        a defined order: the last asynchronous Work, the timing events, the captured graphs (their exec objects are destroyed
+        here, while the context is quiet, not whenever the garbage collector gets to them).  After close() the trainer cannot
+        step any more (use_graph trainers would re-capture; this one refuses)."""
+        if self.__dict__.get("_closed"):
+            return
+        dev = self.engine.device
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize(dev)
+        w = self.__dict__.pop("_last_work", None)
+        if w is not None:
+            w.wait()
+            del w
+        self._ar_events = []
+        for name in ("_g_opt", "_g_late", "_g_fb"):
+            g = getattr(self, name, None)
+            setattr(self, name, None)
+            if g is not None:
+                g.reset()
+                del g
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize(dev)
+        self._closed = True
+
     def _fwd_bwd(self):
         self.engine.forward()
         if self.overlap:
@@ -1317,6 +1347,8 @@ class Trainer:
     def step(self, x_st, y_st, maps=None, lanes=None):
         """One optimisation step on this rank's shard; returns THIS RANK's loss (its shard's mean, not the global mean) as a
         1-element device tensor."""
+        if self.__dict__.get("_closed"):
+            raise MmtError("Trainer.step after close()")
         self.engine.set_batch(x_st, y_st, maps, lanes)
         if self.use_graph:
             if self._g_fb is None:
@@ -1343,6 +1375,7 @@ class Trainer:
                 ev[3].record()
             if work is not None:
                 work.wait()                           # (orders the current stream behind the collective; the host does not block)
+                self._last_work = work                # (close() waits for it on the host before the group may be destroyed)
             for lo, hi in eng.late_ranges:
                 dist.all_reduce(eng.flat_grad[lo:hi], group=self.pg)
             if timed:

@@ -131,12 +131,12 @@ def ln_param_grads(dy, xhat, gw, gb, splitk=1, part_stride=0):
     gb.copy_(dy.double().sum(0).to(gb.dtype))
 
 
-def gemm_group(calls):
+def gemm_group(calls, cache=None):
     for kw in calls:
         gemm(**kw)
 
 
-def ln_param_grads_group(calls):
+def ln_param_grads_group(calls, cache=None):
     for kw in calls:
         ln_param_grads(**kw)
 

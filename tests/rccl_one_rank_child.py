@@ -1,6 +1,9 @@
 """Child process of test_one_rank_rccl_all_reduce_between_graph_replays (not collected by pytest): the training step with a
 one-rank RCCL group -- two backward graphs with the decoder-side bucket reduced beside the second one, and round 1's one-bucket
-form -- against a run without a group.  Prints the verdict and leaves with os._exit (no communicator teardown)."""
+form -- against a run without a group.  Then the ORDERED teardown: every Trainer closed (Trainer.close():
+synchronise, drop the last Work, the timing events and the captured graphs), barrier, synchronise, destroy_process_group, and a
+normal interpreter exit -- the exit code is the real one; the parent test prints this process's stderr when it is not 0 (an
+in-process run under pytest's fd capture had swallowed the C++ side's message of the one abort seen in round 2)."""
 import os
 import sys
 
@@ -32,7 +35,9 @@ def main(rdzv):
             losses.append(float(tr.step(torch.from_numpy(b["x_st"]).to(dev), torch.from_numpy(b["y_st"]).to(dev))))
         if reduce:
             assert tr.allreduce_ms() is not None and tr.allreduce_ms() >= 0.0
-        return losses, torch.cat([p.detach().reshape(-1) for p in reg.parameters()]).clone()
+        out = losses, torch.cat([p.detach().reshape(-1) for p in reg.parameters()]).clone()
+        tr.close()
+        return out
 
     plain = run(False)
     dist.init_process_group("nccl", init_method=f"file://{rdzv}", rank=0, world_size=1, device_id=dev)
@@ -43,16 +48,12 @@ def main(rdzv):
     assert plain[0] == reduced[0] and torch.equal(plain[1], reduced[1])
     assert plain[0] == one_bucket[0] and torch.equal(plain[1], one_bucket[1])
     print("one-rank RCCL step: identical", plain[0], flush=True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print("teardown: destroy_process_group returned", flush=True)
 
 
 if __name__ == "__main__":
-    code = 1
-    try:
-        main(sys.argv[1])
-        code = 0
-    except BaseException:
-        import traceback
-        traceback.print_exc()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(code)
+    main(sys.argv[1])
+    print("child: leaving through the normal interpreter exit", flush=True)

@@ -222,8 +222,11 @@ def test_obtain_encoded_tensors_in_train_mode_drops_the_map_feature():
     assert 0.4 < float(kept.float().mean()) < 0.6
     assert torch.allclose(tr[kept], 2.0 * ev[kept], rtol=1e-6, atol=0)
     assert not torch.equal(tr != 0, tr2 != 0)
+    # F.dropout(..., training=(mode == TRAIN)) does not consult the module's train / eval flag: still dropped
     reg.eval()
-    assert torch.equal(model.obtain_encoded_tensors(ModeKeys.TRAIN, t["x"], t["x_st"], None, t["map"])[6], ev)
+    tr3 = model.obtain_encoded_tensors(ModeKeys.TRAIN, t["x"], t["x_st"], None, t["map"])[6]
+    assert 0.4 < float((tr3 != 0).float().mean()) < 0.6
+    assert torch.equal(model.obtain_encoded_tensors(ModeKeys.EVAL, t["x"], t["x_st"], None, t["map"])[6], ev)
 
 
 class _FixedMask(torch.nn.Module):

@@ -575,3 +575,46 @@ def test_map_patch_extraction_matches_reference_golden():
     assert np.max(np.abs(one.cpu().numpy() - z["ref::rotated"][:3])) <= 2e-4 and one.shape[1:] == (3, 100, 100)
     with pytest.raises(MmtError):
         maps[0].get_cropped_maps(pts[:3], [50, 10, 50, 90], device="cpu")
+
+
+@pytest.mark.parametrize("mode", ["basic", "map_cnn", "lane_cnn"])
+def test_graph_replayed_predict_is_bit_identical_to_eager(mode, decoder_impl):
+    """MultimodalGenerativeCVAE.predict_graphed: the whole predict captured once per shape into a HIP graph --
+    first call eager, second call captures, later calls replay -- equals the eager predict bit for bit, on the captured inputs
+    and on new ones; a parameter update (version counter) drops the graph; mmt_decoder_status is clean after the replays."""
+    from multimodal_transformer_amd import ops
+    if decoder_impl == "persistent":
+        pytest.skip("one family of the capture is enough: the persistent kernel is not the B=128 path")
+    dev = _dev()
+    hp, B, ph = hp_for(mode, False)
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=0)
+    batches = [_to(make_batch(B, 8, ph, seed=s, with_map=(mode == "map_cnn"), with_lanes=(mode == "lane_cnn")), dev) for s in (1, 2, 3)]
+    pick = (lambda o: o[1]) if mode == "lane_cnn" else (lambda o: o[0])
+    want = [pick(model.predict(b[0], b[1], b[4], None, b[5], ph)).clone() for b in batches]
+    torch.cuda.synchronize()
+    model.graph_predict = True
+    got = []
+    for i in (0, 0, 1, 2, 0):          # warm (eager), capture, replay x3
+        b = batches[i]
+        got.append((i, pick(model.predict(b[0], b[1], b[4], None, b[5], ph))))
+    torch.cuda.synchronize()
+    ops.decoder_status()
+    ent = next(iter(model._predict_graphs.values()))
+    assert ent["state"] == "ready" and len(model._predict_graphs) == 1
+    for i, g in got:
+        assert torch.equal(g, want[i]), (mode, i)
+    assert got[2][1].data_ptr() != got[3][1].data_ptr()          # fresh tensors, as predict returns
+    # an in-place parameter update is noticed: the stale graph is dropped, the next calls warm up and re-capture
+    with torch.no_grad():
+        reg.model_dict["VEHICLE/decoder/MLP"].layer_seq.out_mlp.bias.add_(0.125)
+    b = batches[1]
+    moved = pick(model.predict(b[0], b[1], b[4], None, b[5], ph))
+    assert next(iter(model._predict_graphs.values()))["state"] == "warm"
+    again = pick(model.predict(b[0], b[1], b[4], None, b[5], ph))
+    replay = pick(model.predict(b[0], b[1], b[4], None, b[5], ph))
+    torch.cuda.synchronize()
+    assert not torch.equal(moved, want[1]) and torch.equal(moved, again) and torch.equal(moved, replay)
+    model.graph_predict = False
+    assert torch.equal(pick(model.predict(b[0], b[1], b[4], None, b[5], ph)), moved)
+    ops.decoder_status()

@@ -491,6 +491,58 @@ def test_full_config_step_matches_reference_gradient_norms():
         assert abs(after[name]["abs_sum"] - c["abs_sum"]) <= 1e-5 * c["abs_sum"], name
 
 
+def test_full_size_gradients_against_the_fp64_oracle(capsys):
+    """Whose error is the full-size gradient gap?  B=128, T=9, ph=12, 6+6 layers, dropout off: the fp64 autograd
+    of the reference-form oracle (stock torch.nn modules in double precision, full recompute per AR step) is the arbiter; the
+    HIP step's gradients AND the reference's own fp32 autograd (golden ``gradhead::*``, first 256 elements of every gradient,
+    written by tests/golden/make_golden.py from the real reference) are both measured against it, per-output relative error
+    with the tensor's RMS as the floor.  The HIP step must be within 1e-4 of fp64 on every gradient; the golden-vs-fp64 figure
+    is printed beside it and is what the 5e-4 of test_full_config_step_matches_reference_gradient_norms has to absorb."""
+    from multimodal_transformer_amd import training
+    from oracle.reference_form import ReferenceFormModel
+    dev = _dev()
+    z, meta = load_golden("full_basic")
+    hp, B, ph = hp_for("basic", False)
+    hp["autoregressive"] = True
+    model, reg = _model(hp, dev)
+    set_weights(reg.model_dict, False, z)
+    batch = batch_for("basic", False)
+    c = {k: torch.from_numpy(v) for k, v in batch.items()}
+    eng = training.TrainEngine(model, B, c["x_st"].shape[1], ph, dropout=False)
+    eng.set_batch(c["x_st"].to(dev), c["y_st"].to(dev))
+    loss = float(eng.forward())
+    eng.backward()
+    torch.cuda.synchronize()
+    ref = ReferenceFormModel(hp)
+    apply_recipe(ref.m, seed=0)
+    ref.m.double()
+    ref.m.train()
+    for m in ref.m.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    want_loss = ref.train_loss(c["x"].double(), c["x_st"].double(), c["y"].double(), c["y_st"].double(), None, None, ph)
+    want_loss.backward()
+    want = {f"{k}.{pn}": p.grad for k, mod in ref.m.items() for pn, p in mod.named_parameters() if p.grad is not None}
+    assert set(eng.grad_by_name) == set(want)
+    assert abs(loss - float(want_loss)) <= 2e-6 * abs(float(want_loss))
+    assert abs(float(z["train_loss"]) - float(want_loss)) <= 2e-6 * abs(float(want_loss))
+    worst_hip, worst_gold = (0.0, None), (0.0, None)
+    for name, g in eng.grad_by_name.items():
+        w = want[name].numpy()
+        rms = float(np.sqrt(np.mean(w * w))) + 1e-30
+        e_hip = rel_err(g.cpu().numpy(), w)
+        e_gold = rel_err(z["gradhead::" + name], w.reshape(-1)[:256], floor=rms)
+        e_hip_head = rel_err(g.reshape(-1)[:256].cpu().numpy(), w.reshape(-1)[:256], floor=rms)
+        worst_hip = max(worst_hip, (e_hip, name))
+        worst_gold = max(worst_gold, (e_gold, name + f" (HIP on the same 256 elements: {e_hip_head:.2e})"))
+    with capsys.disabled():
+        print(f"\nfull-size gradients vs the fp64 oracle (RMS floor): HIP worst {worst_hip[0]:.3e} at {worst_hip[1]}; "
+              f"reference fp32 autograd (golden heads) worst {worst_gold[0]:.3e} at {worst_gold[1]}")
+    assert worst_hip[0] <= 1e-4, worst_hip
+
+
 def test_graph_replay_equals_eager_and_is_deterministic():
     from multimodal_transformer_amd import training
     from multimodal_transformer_amd.config import make_hyperparams
@@ -740,15 +792,16 @@ def test_register_resident_training_kernels_are_bit_identical_to_the_generic_for
 def test_one_rank_rccl_all_reduce_between_graph_replays(tmp_path):
     """The multi-rank step on one GPU: a one-rank RCCL group, the flat gradient all-reduce issued eagerly between the two HIP-graph
     replays (bench.py --gpus N runs exactly this with N ranks).  A one-rank sum changes nothing: losses and weights equal a run
-    without a group, bit for bit.  Runs in a child process (tests/rccl_one_rank_child.py) that leaves without tearing the RCCL
-    communicator down: that teardown has been seen to abort() the process once in a handful of runs, which would take the whole
-    pytest session with it."""
+    without a group, bit for bit.  Runs in a child process (tests/rccl_one_rank_child.py: torch.distributed is process-global
+    state) which then tears everything down in order -- Trainer.close(), barrier, synchronise, destroy_process_group -- and leaves
+    through the normal interpreter exit: its exit code and stderr are the real ones (VERDICT r2 #2)."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_rank_child.py")
     r = subprocess.run([sys.executable, child, str(tmp_path / "rdzv")], capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0, f"rc={r.returncode}\n" + r.stdout[-2000:] + "\n--- stderr ---\n" + r.stderr[-4000:]
     assert "one-rank RCCL step: identical" in r.stdout, r.stdout[-2000:]
+    assert "teardown: destroy_process_group returned" in r.stdout and "normal interpreter exit" in r.stdout, r.stdout[-2000:]
 
 
 def test_a_step_whose_decode_gave_up_leaves_the_weights_alone():

@@ -262,3 +262,66 @@ def test_gradient_buckets_partition_the_flat_buffer_by_completion_time(monkeypat
     eng.backward_late()
     assert torch.equal(early, eng.flat_grad[lo:hi])          # the late stretch does not touch the early bucket
     assert torch.equal(whole, eng.flat_grad)
+
+
+def test_group_launch_tables_live_as_long_as_their_owner(monkeypatch):
+    """a captured training graph holds the ADDRESS of the device launch table of every group launch.  An
+    owner's cache (TrainEngine._group_cache) therefore never evicts: after > 64 other job lists have gone through the shared,
+    bounded cache and through other owners, the first owner still finds its original table object.  Host-only: the plan / run
+    entry points are stand-ins, the table stays on the CPU."""
+    import ctypes
+    from multimodal_transformer_amd import _lib
+    from multimodal_transformer_amd import _train_kernels as K
+
+    launched = []
+
+    def plan(jobs, n, host, cap, nbytes, nblocks):
+        nbytes._obj.value, nblocks._obj.value = 16 * n, n
+        return 0
+
+    def run(table, njobs, nblocks, stream):
+        launched.append(table.value)
+        return 0
+
+    class _FakeLib:
+        pass
+    monkeypatch.setattr(_lib, "load", lambda: _FakeLib())
+    monkeypatch.setattr(K, "_group_device", lambda: "cpu")
+    monkeypatch.setattr(K, "_stream", lambda: None)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+
+    def joblist(tag, n=3):
+        jobs = (_lib.LnGradJob * n)()
+        for i, J in enumerate(jobs):
+            J.dy, J.M, J.N = 4096 * tag + i, 512, 256
+        return jobs
+
+    owner_a, owner_b = {}, {}
+    first = K._group_launch("ln", joblist(1), plan, run, "fake", cache=owner_a)
+    addr = first.data_ptr()
+    for tag in range(2, 2 + 3 * K._GROUP_TABLES_MAX):          # far more job lists than the shared cache holds
+        K._group_launch("ln", joblist(tag), plan, run, "fake")                     # ad-hoc, shared + bounded
+        K._group_launch("ln", joblist(tag), plan, run, "fake", cache=owner_b)      # another engine
+        K._group_launch("ln", joblist(tag), plan, run, "fake", cache=owner_a)      # the same engine, other shapes
+    assert len(K._GROUP_TABLES) <= K._GROUP_TABLES_MAX
+    assert len(owner_a) == 1 + 3 * K._GROUP_TABLES_MAX           # nothing of an owner's is ever evicted
+    again = K._group_launch("ln", joblist(1), plan, run, "fake", cache=owner_a)
+    assert again is first and again.data_ptr() == addr and launched[-1] == addr
+    # a capture may not lean on the shared cache: its entries can be evicted under a live graph
+    K._group_launch("ln", joblist(7), plan, run, "fake")
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    with pytest.raises(_lib.MmtError):
+        K._group_launch("ln", joblist(7), plan, run, "fake")
+    K._group_launch("ln", joblist(1), plan, run, "fake", cache=owner_a)            # an owner's table replays under capture
+
+
+def test_train_engine_owns_its_group_tables(monkeypatch):
+    from multimodal_transformer_amd import _train_kernels as K
+    training, model, reg, z, meta, hp, x_st, y_st, ph = _tiny_engine(monkeypatch)
+    seen = []
+    monkeypatch.setattr(K, "gemm_group", lambda calls, cache=None: seen.append(cache))
+    monkeypatch.setattr(K, "ln_param_grads_group", lambda calls, cache=None: seen.append(cache))
+    eng = training.TrainEngine(model, x_st.shape[0], x_st.shape[1], ph)
+    eng._deferred = ([], [])
+    eng._flush_wgrads()
+    assert seen and all(c is eng._group_cache for c in seen)

@@ -81,3 +81,48 @@ def test_static_scratch_decode_equals_workspace_decode(impl):
         assert torch.isnan(p_big).all()
     finally:
         ops.decoder_select("auto")
+
+
+def test_static_scratch_decode_replays_from_a_hip_graph():
+    """The advertised caller: after one eager call (the per-device set-up queries are not stream operations, include/mmt_amd.h),
+    a decode captured into a HIP graph replays bit for bit -- also on new inputs written into the captured buffers."""
+    from multimodal_transformer_amd import _lib, ops
+    from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    hp = make_hyperparams("basic", history=8, horizon=12)
+    reg = ModelRegistrar("/tmp", dev)
+    MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, [])
+    apply_recipe(reg.model_dict, seed=0)
+    enc = reg.model_dict["VEHICLE/node_history_encoder"]
+    dec = reg.model_dict["VEHICLE/decoder/transformer_decoder"]
+    packed = dec.packed(head=reg.model_dict["VEHICLE/decoder/MLP"])
+    B = 128
+    xs = [torch.from_numpy(make_batch(B, 8, 12, seed=s)["x_st"]).to(dev) for s in (5, 6)]
+    memory, pad = enc.forward_with_mask(xs[0])
+    memory, pad = memory.clone(), pad.clone()
+    start = xs[0][:, -1, 0:2].contiguous()
+    rc, want0, _ = _decode(lib, packed.desc, memory, pad, start, 12, static=True)         # eager first call: set-up happens here
+    assert rc == 0, lib.mmt_last_error()
+    torch.cuda.synchronize()
+    pred = torch.empty(B, 12, 2, dtype=torch.float32, device=dev)
+    h = torch.empty(B, 12, packed.desc.n_out, dtype=torch.float32, device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = lib.mmt_decoder_forward_static(C.byref(packed.desc), _ptr(memory), _ptr(pad), _ptr(start), None, 0, None, 0, None,
+                                            B, 9, 12, _ptr(pred), _ptr(h), st)
+    assert rc == 0, lib.mmt_last_error()
+    pred.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pred, want0)
+    m1, p1 = enc.forward_with_mask(xs[1])
+    memory.copy_(m1), pad.copy_(p1), start.copy_(xs[1][:, -1, 0:2])
+    g.replay()
+    torch.cuda.synchronize()
+    got1 = pred.clone()
+    rc, want1, _ = _decode(lib, packed.desc, memory, pad, start, 12, static=True)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(got1, want1) and not torch.equal(want1, want0)
+    ops.decoder_status()
