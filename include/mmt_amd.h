@@ -241,7 +241,7 @@ typedef struct {
   const float *src;
   float *dst;
   int64_t total;
-  int32_t kind, n, k, ldw, col0, nparts, part_rows, slice_rows, nslices, pad_;
+  int32_t kind, n, k, ldw, col0, nparts, part_rows, slice_rows, nslices, tr;   /* tr (kinds 2, 3): the matrix is the transpose of src */
 } mmt_pack_job;
 int mmt_pack_jobs(const mmt_pack_job *table_dev, int njobs, void *stream);
 
@@ -353,6 +353,50 @@ int mmt_decoder_dropout_supported(const mmt_decoder *dec, int B, int T, int ph);
 int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim, int B, int T,
                                 int ph, float *pred_st, float *workspace, const mmt_decoder_dropout *drop, void *stream);
+
+/* ---- reverse-time sweep of the training step as ONE weight-stationary pipeline launch (round 3) -----------------------------
+ * Replaces the per-(step, layer) kernel chain of the decoder backward (the autograd of train.py:248 `loss.backward()` through
+ * mgcvae.py:432-446's position feedback; training.TrainEngine._sweep here): same inputs (the forward stash), same outputs (every
+ * gradient buffer the deferred weight-gradient GEMMs read), dropout-free graph, autoregressive decode, decoder/MLP head with one
+ * hidden layer (Basic / Lane configurations).  No counterpart in the reference (which calls autograd).
+ * Stage kinds index the [3] arrays: 0 = feed forward (LayerNorm3), 1 = cross attention (LayerNorm2), 2 = self attention
+ * (LayerNorm1).  w1 / w2 / w2k / w2v / w_ofc are 4x4x1-order packs (mmt_pack_jobs kinds 2 / 3 with tr = 1: the sweep multiplies
+ * by W where the forward multiplies by W^T):
+ *   w1[0] = first(linear2.weight^T, slices of d_ff/H rows)   w2[0] = second(linear1.weight^T, K slices of d_ff/H)
+ *   w1[1] = first(cross out_proj^T, slices of dh rows)       w2[1] = second(cross in_proj_weight[:d]^T, K slices of dh)
+ *   w1[2] = first(self out_proj^T, slices of dh rows)        w2[2] / w2k / w2v = second(self in_proj_weight[q | k | v rows]^T)
+ *   w_ofc = second(output_fc.weight^T, one K slice of n_out)
+ * Stash layouts are the training step's: step-major (ph, B, .) rows s*B + b; p1 (B,H,ph,ph), p2 (B,H,ph,T); mkv / gmkv (B*T, 2d).
+ * gqkv's k | v columns and gmkv must be ZERO on entry (they accumulate); G is (ph + 1, B, 2) with dL/dpos[t] in row t = 1..ph on
+ * entry and the total gradient at pos[t] on return.  A sweep whose hand-offs time out (0.2 s) writes NaN to *poison, raises the
+ * fault that mmt_decoder_status reports, and leaves the gradient buffers undefined. */
+typedef struct {
+  const float *w1[3], *w2[3], *w2k, *w2v;
+  const float *gamma[3];                  /* norm3 / norm2 / norm1 .weight */
+  const float *xhat[3], *rstd[3];         /* stash of those LayerNorms: (ph,B,d), (ph,B) */
+  float *gdy[3], *gdx[3];                 /* out: gradient at each LayerNorm's output / input, (ph,B,d) */
+  const float *f1;                        /* relu(linear1) hidden, (ph,B,d_ff) */
+  float *gf1;                             /* out: its gradient */
+  const float *cq, *mkv, *p2;             /* cross attention: queries (ph,B,d), memory K|V (B*T,2d), probabilities */
+  float *gcq, *gmkv;
+  const float *qkv, *p1;                  /* self attention: q|k|v (ph,B,3d), probabilities */
+  float *gqkv;
+} mmt_sweep_layer;
+typedef struct {
+  int32_t B, T, ph, d, H, nlayers, d_ff, n_out, n_pos, pad_;
+  mmt_sweep_layer layer[MMT_MAX_LAYERS];
+  float *G;                               /* (ph+1, B, 2) */
+  float *gx0;                             /* out: gradient at the embedded tokens, (ph,B,d) */
+  const float *w_in;                      /* decoder input_fc.weight (d, 2), natural layout */
+  const float *w_hout, *h_gamma, *w_h0;   /* decoder/MLP: out Linear weight (2, n_out), LayerNorm weight, hidden Linear weight (n_out, n_out) */
+  const float *w_ofc;
+  const float *h_hu, *h_xhat, *h_rstd;    /* head tape: relu(LN(.)) (ph,B,n_out), xhat, rstd (ph,B) */
+  float *h_ghum, *h_ghz, *h_gho;          /* out: masked dy of the head's LayerNorm, its dx, gradient at output_fc's output */
+  float *poison;                          /* 1 float: NaN when the sweep gave up (the step's loss / optimizer guard), may be NULL */
+} mmt_sweep_pipe;
+int mmt_sweep_pipe_supported(const mmt_sweep_pipe *args);
+size_t mmt_sweep_pipe_workspace_floats(const mmt_sweep_pipe *args);
+int mmt_sweep_pipe_run(const mmt_sweep_pipe *args, float *workspace, void *stream);
 
 /* ---- ViT.forward (vit_pytorch 0.33.2 architecture; parity unpinned): maps (B,C,S,S) -> (B,n_out) ------------ */
 int mmt_vit_forward(const mmt_vit *vit, const float *maps, int B, float *out, void *stream);

@@ -109,7 +109,20 @@ class AttnArgs(C.Structure):
 
 class PackJob(C.Structure):
     _fields_ = [("src", fptr), ("dst", fptr), ("total", C.c_int64)] + \
-               [(n, C.c_int32) for n in ("kind", "n", "k", "ldw", "col0", "nparts", "part_rows", "slice_rows", "nslices", "pad_")]
+               [(n, C.c_int32) for n in ("kind", "n", "k", "ldw", "col0", "nparts", "part_rows", "slice_rows", "nslices", "tr")]
+
+
+class SweepLayer(C.Structure):
+    _fields_ = [("w1", fptr * 3), ("w2", fptr * 3), ("w2k", fptr), ("w2v", fptr), ("gamma", fptr * 3), ("xhat", fptr * 3),
+                ("rstd", fptr * 3), ("gdy", fptr * 3), ("gdx", fptr * 3), ("f1", fptr), ("gf1", fptr), ("cq", fptr), ("mkv", fptr),
+                ("p2", fptr), ("gcq", fptr), ("gmkv", fptr), ("qkv", fptr), ("p1", fptr), ("gqkv", fptr)]
+
+
+class SweepPipe(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "T", "ph", "d", "H", "nlayers", "d_ff", "n_out", "n_pos", "pad_")] + \
+               [("layer", SweepLayer * MMT_MAX_LAYERS)] + \
+               [(n, fptr) for n in ("G", "gx0", "w_in", "w_hout", "h_gamma", "w_h0", "w_ofc", "h_hu", "h_xhat", "h_rstd", "h_ghum",
+                                    "h_ghz", "h_gho", "poison")]
 
 
 class LnGradJob(C.Structure):
@@ -149,6 +162,9 @@ SIGNATURES = {
     "mmt_decoder_dropout_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     "mmt_decoder_forward_dropout": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int,
                                               C.c_int, fptr, fptr, C.POINTER(DecoderDropout), C.c_void_p]),
+    "mmt_sweep_pipe_supported": (C.c_int, [C.POINTER(SweepPipe)]),
+    "mmt_sweep_pipe_workspace_floats": (C.c_size_t, [C.POINTER(SweepPipe)]),
+    "mmt_sweep_pipe_run": (C.c_int, [C.POINTER(SweepPipe), fptr, C.c_void_p]),
     "mmt_decoder_status": (C.c_int, [C.c_void_p]),
     "mmt_decoder_last_path": (C.c_int, []),
     "mmt_debug_decoder_stall": (C.c_int, [C.c_int]),

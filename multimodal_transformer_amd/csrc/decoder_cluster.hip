@@ -2428,8 +2428,10 @@ bool mfma4_fits(const mmt_decoder *dec) {
   return true;
 }
 
+// tr: the matrix is the TRANSPOSE of the array at w (element (row, col) = w[col * ldw + row]): the backward pipeline multiplies
+// by W where the forward multiplies by W^T (decoder_bwd_pipe.cuh)
 __device__ __forceinline__ float lin4_first_elem(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
-                                                 size_t i) {
+                                                 size_t i, bool tr = false) {
   const Lin4 L = lin4(slice_rows / 4, k / 4);
   const int e = i & 3, lane = (i >> 2) & 63, wv = (i >> 8) & 7;
   size_t rest = i >> 11;
@@ -2438,21 +2440,24 @@ __device__ __forceinline__ float lin4_first_elem(const float *__restrict__ w, in
   const int p = rest % nparts, g = rest / nparts;
   const int b = lane >> 2, j = lane & 3, cgl = b & (L.cgw - 1), kq = (b >> L.lg_cgw) * L.q + t;
   const int row = p * part_rows + g * slice_rows + (wv * L.cgw + cgl) * 4 + j;
-  return kq < k / 4 ? w[(size_t)row * ldw + 4 * kq + e] : 0.f;
+  if (kq >= k / 4) return 0.f;
+  return tr ? w[(size_t)(4 * kq + e) * ldw + row] : w[(size_t)row * ldw + 4 * kq + e];
 }
 __global__ void mmt_pack_lin4_first_kernel(const float *__restrict__ w, int ldw, int nparts, int part_rows, int slice_rows, int k,
                                            size_t total, float *__restrict__ dst) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + thread_idx();
   if (i < total) dst[i] = lin4_first_elem(w, ldw, nparts, part_rows, slice_rows, k, i);
 }
-__device__ __forceinline__ float lin4_second_elem(const float *__restrict__ w, int ldw, int n, int slice_k, size_t i) {
+__device__ __forceinline__ float lin4_second_elem(const float *__restrict__ w, int ldw, int n, int slice_k, size_t i, bool tr = false) {
   const Lin4 L = lin4(n / 4, slice_k / 4);
   const int e = i & 3, lane = (i >> 2) & 63, wv = (i >> 8) & 7;
   const size_t rest = i >> 11;
   const int t = rest % L.q, g = rest / L.q;
   const int b = lane >> 2, j = lane & 3, cgl = b & (L.cgw - 1), kq = (b >> L.lg_cgw) * L.q + t;
   const int row = (wv * L.cgw + cgl) * 4 + j;
-  return kq < slice_k / 4 ? w[(size_t)row * ldw + (size_t)g * slice_k + 4 * kq + e] : 0.f;
+  if (kq >= slice_k / 4) return 0.f;
+  const size_t col = (size_t)g * slice_k + 4 * kq + e;
+  return tr ? w[col * ldw + row] : w[(size_t)row * ldw + col];
 }
 __global__ void mmt_pack_lin4_second_kernel(const float *__restrict__ w, int ldw, int n, int slice_k, size_t total,
                                             float *__restrict__ dst) {
@@ -2474,13 +2479,15 @@ __global__ __launch_bounds__(256) void mmt_pack_jobs_kernel(const mmt_pack_job *
       const int row = slab * 16 + (lane & 15), col = chunk * 16 + (lane >> 4) * 4 + e;
       v = (row < J.n && col < J.k) ? J.src[(size_t)row * J.ldw + J.col0 + col] : 0.f;
     } else if (J.kind == 2) {
-      v = lin4_first_elem(J.src, J.ldw, J.nparts, J.part_rows, J.slice_rows, J.k, i);
+      v = lin4_first_elem(J.src, J.ldw, J.nparts, J.part_rows, J.slice_rows, J.k, i, J.tr != 0);
     } else {
-      v = lin4_second_elem(J.src, J.ldw, J.n, J.slice_rows, i);
+      v = lin4_second_elem(J.src, J.ldw, J.n, J.slice_rows, i, J.tr != 0);
     }
     J.dst[i] = v;
   }
 }
+
+#include "decoder_bwd_pipe.cuh"
 
 }  // namespace
 
@@ -2938,4 +2945,64 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
                 : launch_phases<32, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st);
   return cpw2 ? launch_phases<16, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st)
               : launch_phases<16, 1, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st);
+}
+
+
+// ------------------------------------------------------------------------------- backward sweep pipeline (decoder_bwd_pipe.cuh)
+static bool sweep_pipe_static_ok(const mmt_sweep_pipe *a) {
+  if (!a) return false;
+  if (a->d != 256 || a->H != 8 || a->d_ff != 64 * a->H || a->n_out != 32 || a->n_pos != 2) return false;
+  if (a->nlayers < 1 || a->nlayers > MMT_MAX_LAYERS || 3 * a->nlayers > 25) return false;      // tag generations: see pipe_applies
+  if (a->T < 1 || a->T > KMAX || a->ph < 1 || a->ph > KMAX || a->B < 1 || a->B > PIPE_MAX_B) return false;
+  return true;
+}
+extern "C" int mmt_sweep_pipe_supported(const mmt_sweep_pipe *a) {
+  if (!sweep_pipe_static_ok(a) || dec_env().no_fused || dec_env().no_pipe || getenv("MMT_NO_PIPELINE_SWEEP")) return 0;
+  const int dev = cur_dev(), ncu = dev_ncu(dev);
+  if (g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) return 0;
+  const PipeGeom pg = pipe_geom(a->nlayers, a->H, (a->B + 3) / 4, ncu);
+  if (pg.R < 1 || pg.grid > ncu) return 0;
+  int nb = 0;
+  const size_t lds = bwd_lds_floats(a->d) * sizeof(float);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)mmt_bwd_pipe4_kernel<32, 256, 64>, CNT, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nb >= 1;
+}
+extern "C" size_t mmt_sweep_pipe_workspace_floats(const mmt_sweep_pipe *a) {
+  if (!sweep_pipe_static_ok(a)) return 0;
+  const size_t NC = (a->B + 3) / 4, d = a->d;
+  return 2 * NC * a->H * 16 * d + 2 * NC * 16 * d + NC * 4 * d + 64;
+}
+extern "C" int mmt_sweep_pipe_run(const mmt_sweep_pipe *a, float *ws, void *stream) {
+  if (!sweep_pipe_static_ok(a) || !ws) return mmt_set_error(MMT_EINVAL, "mmt_sweep_pipe_run: unsupported geometry or no workspace");
+  if (!mmt_sweep_pipe_supported(a)) return mmt_set_error(MMT_EINVAL, "mmt_sweep_pipe_run: the pipeline does not fit this device (or is disabled)");
+  hipStream_t st = (hipStream_t)stream;
+  const int dev = cur_dev(), ncu = dev_ncu(dev);
+  BwdPipeArgs f;
+  f.a = *a;
+  const size_t NC = (a->B + 3) / 4, d = a->d;
+  const PipeGeom pg = pipe_geom(a->nlayers, a->H, (int)NC, ncu);
+  float *p = ws;
+  f.sync = reinterpret_cast<unsigned *>(p);
+  p += 64;
+  const size_t npart = NC * a->H * 16 * d, nres = NC * 16 * d;
+  f.part[0] = p, f.part[1] = p + npart;
+  p += 2 * npart;
+  f.xres[0] = p, f.xres[1] = p + nres;
+  p += 2 * nres;
+  f.x0buf = p;
+  p += NC * 4 * d;
+  f.NC = (int)NC, f.R = pg.R, f.NHW = pg.NHW;
+  f.test_stall = g_test_stall.load(std::memory_order_relaxed);
+  // every hand-off word starts as the 0xFFFFFFFF no tag matches; the time-out word as 0
+  hipLaunchKernelGGL(mmt_bwd_pipe_fill_kernel, dim3(512), dim3(256), 0, st, ws, (size_t)(p - (ws + 64)) / 4);
+  CL_CHECK("mmt_bwd_pipe_fill_kernel");
+  const size_t lds = bwd_lds_floats(a->d) * sizeof(float);
+  hipLaunchKernelGGL((mmt_bwd_pipe4_kernel<32, 256, 64>), dim3(pg.grid), dim3(CNT), lds, st, f);
+  CL_CHECK("mmt_bwd_pipe4_kernel");
+  hipLaunchKernelGGL(mmt_bwd_pipe_check_kernel, dim3(1), dim3(64), 0, st, (const unsigned *)f.sync, a->poison);
+  CL_CHECK("mmt_bwd_pipe_check_kernel");
+  return MMT_OK;
 }

@@ -82,23 +82,26 @@ class _Packer:
         self.jobs.append(("lin", L, w, b, row0, col0, n, k, woff, boff))
         return L
 
-    def lin4_first(self, w, nparts, part_rows, slice_rows, nslices):
+    def lin4_first(self, w, nparts, part_rows, slice_rows, nslices, tr=False):
         """Plan a copy of a row-split linear in the order of the 4-agent-cluster kernels (mmt_pack_lin4_first); None when
-        the geometry is not one they handle.  ``w`` starts at the first row used (a view is fine, row stride = w.stride(0))."""
-        n = self.lib.mmt_lin4_first_floats(nparts, slice_rows, w.shape[1], nslices)
-        if not n:
+        the geometry is not one they handle.  ``w`` starts at the first row used (a view is fine, row stride = w.stride(0)).
+        ``tr``: the matrix to pack is ``w``'s TRANSPOSE (the backward sweep multiplies by W where the forward takes W^T)."""
+        k = w.shape[0] if tr else w.shape[1]
+        n = self.lib.mmt_lin4_first_floats(nparts, slice_rows, k, nslices)
+        if not n or (tr and (nparts != 1 or w.shape[1] != slice_rows * nslices)):
             return None
         holder = [None]
-        self.jobs.append(("lin4a", holder, w, nparts, part_rows, slice_rows, nslices, self.arena.reserve(n)))
+        self.jobs.append(("lin4a", holder, w, nparts, part_rows, slice_rows, nslices, self.arena.reserve(n), bool(tr)))
         return holder
 
-    def lin4_second(self, w, slice_k, nslices):
-        """Same for a column-split linear (out_proj, linear2): mmt_pack_lin4_second."""
-        n = self.lib.mmt_lin4_second_floats(w.shape[0], slice_k, nslices)
-        if not n or w.shape[1] != slice_k * nslices:
+    def lin4_second(self, w, slice_k, nslices, tr=False):
+        """Same for a column-split linear (out_proj, linear2): mmt_pack_lin4_second.  ``tr`` as in ``lin4_first``."""
+        rows, cols = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
+        n = self.lib.mmt_lin4_second_floats(rows, slice_k, nslices)
+        if not n or cols != slice_k * nslices:
             return None
         holder = [None]
-        self.jobs.append(("lin4b", holder, w, slice_k, nslices, self.arena.reserve(n)))
+        self.jobs.append(("lin4b", holder, w, slice_k, nslices, self.arena.reserve(n), bool(tr)))
         return holder
 
     def norm(self, g, b):
@@ -145,14 +148,20 @@ class _Packer:
                     job(0, fb.data_ptr() + 4 * row0, boff, n, n=n)
                     L.b = A.addr(boff)
             elif jb[0] == "lin4a":
-                _, holder, w, nparts, part_rows, slice_rows, nslices, off = jb
-                job(2, w.data_ptr(), off, self.lib.mmt_lin4_first_floats(nparts, slice_rows, w.shape[1], nslices),
-                    ldw=w.stride(0), nparts=nparts, part_rows=part_rows, slice_rows=slice_rows, k=w.shape[1], nslices=nslices)
+                _, holder, w, nparts, part_rows, slice_rows, nslices, off, tr = jb
+                k = w.shape[0] if tr else w.shape[1]
+                if w.stride(1) != 1:
+                    raise MmtError("lin4_first: the source rows must have unit stride")
+                job(2, w.data_ptr(), off, self.lib.mmt_lin4_first_floats(nparts, slice_rows, k, nslices),
+                    ldw=w.stride(0), nparts=nparts, part_rows=part_rows, slice_rows=slice_rows, k=k, nslices=nslices, tr=int(tr))
                 holder[0] = A.addr(off)
             elif jb[0] == "lin4b":
-                _, holder, w, slice_k, nslices, off = jb
-                job(3, w.data_ptr(), off, self.lib.mmt_lin4_second_floats(w.shape[0], slice_k, nslices), ldw=w.stride(0),
-                    n=w.shape[0], slice_rows=slice_k, nslices=nslices)
+                _, holder, w, slice_k, nslices, off, tr = jb
+                rows = w.shape[1] if tr else w.shape[0]
+                if w.stride(1) != 1:
+                    raise MmtError("lin4_second: the source rows must have unit stride")
+                job(3, w.data_ptr(), off, self.lib.mmt_lin4_second_floats(rows, slice_k, nslices), ldw=w.stride(0),
+                    n=rows, slice_rows=slice_k, nslices=nslices, tr=int(tr))
                 holder[0] = A.addr(off)
             elif jb[0] == "norm":
                 _, Nn, g, b, goff, boff = jb

@@ -388,9 +388,27 @@ class _DropPlan:
         self.rng.copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
 
     def generate(self):
+        if self.frozen:
+            return
         for i, (p, lo, hi) in enumerate(self.regions):
             K.dropout_mask(self.pool[lo:hi], p, self.rng, i)
         K.rng_advance(self.rng)
+
+    frozen = False
+
+    def inject(self, keep):
+        """Use GIVEN keep masks {site: bool / uint8 tensor shaped like the site} from now on instead of drawing them (tests: the
+        masks the real reference was run with, tests/golden/*_dropout.npz).  Every active site must be given, nothing else."""
+        active = {n for n, v in self.view.items() if v is not None}
+        if set(keep) != active:
+            raise MmtError(f"inject: masks for {sorted(set(keep) ^ active)} missing or unknown")
+        for n, m in keep.items():
+            dst = self.view[n][0]
+            m = torch.as_tensor(m)
+            if m.numel() != dst.numel():
+                raise MmtError(f"inject: site {n} has {dst.numel()} elements, mask has {m.numel()}")
+            dst.copy_((m.reshape(dst.shape) != 0).to(torch.uint8))
+        self.frozen = True
 
     def masks(self):
         """{site: bool tensor} of the masks the last ``generate`` drew (tests inject them into the oracle)."""
@@ -1011,6 +1029,94 @@ class TrainEngine:
         self.backward_early()
         self.backward_late()
 
+    # ------------------------------------------------------------------ the sweep as one pipeline launch (mmt_sweep_pipe_run)
+    sweep_pipeline = True          # False: always the launch-per-kernel sweep (tests compare the two)
+
+    def _sweep_pipe(self):
+        """The descriptor of the one-launch sweep (csrc/decoder_bwd_pipe.cuh), or None where it does not apply: dropout-free
+        autoregressive graph, Basic / Lane configuration, the shipped decoder geometry, decoder/MLP with one hidden layer."""
+        sp = self.__dict__.get("_sweep_pipe_state")
+        if sp is not None:
+            return sp or None
+        self._sweep_pipe_state = False
+        dev = torch.device(self.device)
+        self.sweep_pipe_why = "configuration (device / teacher forcing / map mode / dropout / head depth)"
+        if (dev.type != "cuda" or not self.sweep_pipeline or self.teacher_forced or self.map_mode or self.drop.active
+                or len(self.head_tape.hidden) != 1):
+            return None
+        from . import _lib
+        import ctypes as C
+        S, d, H, L = self.s, self.d, self.H, self.Ld
+        lin0, ln0 = self.head_tape.hidden[0]
+        out = self.head_tape.out
+        self.sweep_pipe_why = "head widths"
+        if tuple(lin0.weight.shape) != (self.n_out, self.n_out) or tuple(out.weight.shape) != (self.n_pos, self.n_out):
+            return None
+        A = _lib.SweepPipe()
+        A.B, A.T, A.ph, A.d, A.H, A.nlayers, A.d_ff, A.n_out, A.n_pos = self.B, self.T, self.ph, d, H, L, self.f_dec, self.n_out, self.n_pos
+        lib = _lib.load()
+        self.sweep_pipe_why = "geometry (mmt_sweep_pipe_workspace_floats)"
+        if not lib.mmt_sweep_pipe_workspace_floats(C.byref(A)):
+            return None
+        DH, FS = d // H, self.f_dec // H
+        pk = ops._Packer(dev)
+        dec = self.dec
+        holders = []
+        for l, lay in enumerate(dec.transformer_decoder.layers):
+            sa, ca = lay.self_attn, lay.multihead_attn
+            wq, wk, wv = sa.in_proj_weight[:d], sa.in_proj_weight[d:2 * d], sa.in_proj_weight[2 * d:]
+            holders.append(dict(
+                w1=[pk.lin4_first(lay.linear2.weight, 1, 0, FS, H, tr=True), pk.lin4_first(ca.out_proj.weight, 1, 0, DH, H, tr=True),
+                    pk.lin4_first(sa.out_proj.weight, 1, 0, DH, H, tr=True)],
+                w2=[pk.lin4_second(lay.linear1.weight, FS, H, tr=True), pk.lin4_second(ca.in_proj_weight[:d], DH, H, tr=True),
+                    pk.lin4_second(wq, DH, H, tr=True)],
+                w2k=pk.lin4_second(wk, DH, H, tr=True), w2v=pk.lin4_second(wv, DH, H, tr=True)))
+        ofc = pk.lin4_second(dec.output_fc.weight, self.n_out, 1, tr=True)
+        self.sweep_pipe_why = "weight packs"
+        packs = [ofc] + [h for hd in holders for h in (hd["w1"] + hd["w2"] + [hd["w2k"], hd["w2v"]])]
+        if any(h is None for h in packs):          # (a holder is a one-element list, filled by finish())
+            return None
+        pk.finish()
+        P = lambda t: t.data_ptr()
+        for l, lay in enumerate(dec.transformer_decoder.layers):
+            Wl, hd = A.layer[l], holders[l]
+            for k in range(3):
+                Wl.w1[k], Wl.w2[k] = hd["w1"][k][0], hd["w2"][k][0]
+            Wl.w2k, Wl.w2v = hd["w2k"][0], hd["w2v"][0]
+            for k, (ln, xh, rs, gdy, gdx) in enumerate(((lay.norm3, S.xhat3[l], S.rstd3[l], S.gx[l + 1], S.gf2m[l]),
+                                                       (lay.norm2, S.xhat2[l], S.rstd2[l], S.gx2[l], S.go2m[l]),
+                                                       (lay.norm1, S.xhat1[l], S.rstd1[l], S.gx1[l], S.go1m[l]))):
+                Wl.gamma[k], Wl.xhat[k], Wl.rstd[k], Wl.gdy[k], Wl.gdx[k] = P(ln.weight), P(xh), P(rs), P(gdy), P(gdx)
+            Wl.f1, Wl.gf1 = P(S.f1[l]), P(S.gf1[l])
+            Wl.cq, Wl.mkv, Wl.p2, Wl.gcq, Wl.gmkv = P(S.cq[l]), P(S.mkv[l]), P(S.p2[l]), P(S.gcq[l]), P(S.gmkv[l])
+            Wl.qkv, Wl.p1, Wl.gqkv = P(S.qkv[l]), P(S.p1[l]), P(S.gqkv[l])
+        ht = self.head_tape
+        A.G, A.gx0, A.w_in = P(S.G), P(S.gx[0]), P(dec.input_fc.weight)
+        A.w_hout, A.h_gamma, A.w_h0, A.w_ofc = P(out.weight), P(ln0.weight), P(lin0.weight), ofc[0]
+        A.h_hu, A.h_xhat, A.h_rstd = P(ht.hu[0]), P(ht.hxhat[0]), P(ht.hrstd[0])
+        A.h_ghum, A.h_ghz, A.h_gho, A.poison = P(ht.ghum[0]), P(ht.ghz[0]), P(ht.gin), P(self.loss)
+        self.sweep_pipe_why = "mmt_sweep_pipe_supported (device fit / disabled)"
+        if not lib.mmt_sweep_pipe_supported(C.byref(A)):
+            return None
+        ws = torch.empty(int(lib.mmt_sweep_pipe_workspace_floats(C.byref(A))), dtype=torch.float32, device=dev)
+        self.sweep_pipe_why = "in use"
+        self._sweep_pipe_state = (A, pk, ws)
+        return self._sweep_pipe_state
+
+    def _sweep_on_pipeline(self):
+        """True when the sweep went out as the one pipeline launch."""
+        sp = self._sweep_pipe()
+        if sp is None:
+            return False
+        from . import _lib
+        import ctypes as C
+        A, pk, ws = sp
+        if not _lib.load().mmt_sweep_pipe_supported(C.byref(A)):      # e.g. the one-launch forms were disabled after a time-out
+            return False
+        pk.run()                                   # the transposed weight packs follow the parameters (one launch)
+        _lib.check(_lib.load().mmt_sweep_pipe_run(C.byref(A), C.c_void_p(ws.data_ptr()), ops._stream()), "mmt_sweep_pipe_run")
+        return True
+
     def backward_early(self):
         """The sweep and every gradient of ``early_range`` (decoder, head, map encoder, fusion/hist_map)."""
         S, B, T, d, H, ph = self.s, self.B, self.T, self.d, self.H, self.ph
@@ -1023,7 +1129,9 @@ class TrainEngine:
         # inside the captured graph: 7.02 ms (1 way) / 7.76 (2) / 8.28 (4) per step at B = 128: every range's chain is as long
         # as the whole batch's (the kernels already spread the agents over workgroups), so the default is one range.
         chunks = self._sweep_chunks()
-        if len(chunks) == 1:
+        if self._sweep_on_pipeline():
+            pass
+        elif len(chunks) == 1:
             self._sweep(0, B)
         else:
             cur = torch.cuda.current_stream(self.device)

@@ -256,6 +256,98 @@ def run_nonar():
     print("tiny_basic_nonar train_loss", float(out["train_loss"]))
 
 
+def run_dropout():
+    """Dropout PLACEMENT pinned against the real reference: the reference's own ``train_loss`` in training mode
+    with ``torch.nn.functional.dropout`` replaced by a function that multiplies by PRE-DRAWN keep masks (seeded generator) and
+    records which module asked -- every ``nn.Dropout`` of the reference's modules calls ``F.dropout`` at run time
+    (Transformer_model.py:28-30,77-79,126-129), and so does ``F.dropout(encoded_map, ...)`` at mgcvae.py:291-293.  The
+    attention-probability dropout lives inside ``scaled_dot_product_attention`` where nothing can be injected: it is switched
+    off (``nn.MultiheadAttention.dropout = 0``) and stays pinned to this repository's restatement only.
+
+    Two fixtures, tiny config, weights / inputs of the tiny goldens:
+      tiny_basic_nonar_dropout  teacher-forced training (ONE decoder pass: every decoder site is hit exactly once): PE (enc, dec),
+                                dropout1/2 + feed-forward inner of every encoder layer, dropout1/2/3 + inner of every decoder layer
+      tiny_map_cnn_dropout      autoregressive Map_encoding_CNN with the decoder's probabilities at 0 (its passes would redraw):
+                                encoder sites + the map feature (p = 0.5)
+    Stored: keep masks under the training engine's site names in ITS layout (encoder rows b*T+t, decoder step-major), the
+    loss and every gradient."""
+    import torch.nn.functional as Fn
+    tiny_tr = {"nlayers": 2, "nhead": 2, "in_dim": 32, "fdim": 64, "output_size": 32}
+    for tag, mode, ar in (("tiny_basic_nonar_dropout", "basic", False), ("tiny_map_cnn_dropout", "map_cnn", True)):
+        hp = make_hyperparams(mode, history=4, horizon=3, autoregressive=ar, transformer=tiny_tr)
+        B, ph = 4, 3
+        model, reg = build_reference(hp, seed=1234)
+        apply_recipe(reg.model_dict, seed=0)
+        batch = make_batch(B, history=hp["maximum_history_length"], horizon=ph, seed=1, with_map=(mode == "map_cnn"))
+        x, x_st, y, y_st, lanes, maps = tensors(batch)
+        site_of = {}
+        for key, mod in reg.model_dict.items():
+            side = "enc" if key.endswith("node_history_encoder") else ("dec" if key.endswith("transformer_decoder") else None)
+            for name, m in mod.named_modules():
+                if isinstance(m, nn.MultiheadAttention):
+                    m.dropout = 0.0                    # (inside SDPA: cannot be injected)
+                if not isinstance(m, nn.Dropout):
+                    continue
+                if side is None:
+                    raise RuntimeError(f"unexpected nn.Dropout {key}.{name}")
+                if side == "dec" and ar:
+                    m.p = 0.0                          # the AR loop re-runs the decoder: fresh masks per pass, not injectable once
+                parts = name.split(".")
+                if name == "pos_encoder.dropout":
+                    site = f"{side}.pe"
+                else:
+                    l, leaf = int(parts[2]), parts[3]
+                    site = f"{side}{l}." + {"dropout": "ff", "dropout1": "drop1", "dropout2": "drop2", "dropout3": "drop3"}[leaf]
+                site_of[id(m)] = site
+        current = [None]
+        for key, mod in reg.model_dict.items():
+            for m in mod.modules():
+                if isinstance(m, nn.Dropout):
+                    m.register_forward_pre_hook(lambda mm, inp: current.__setitem__(0, site_of[id(mm)]))
+        gen = torch.Generator().manual_seed(4321)
+        drawn, probs = {}, {}
+
+        def fake_dropout(input, p=0.5, training=True, inplace=False):
+            site, current[0] = current[0], None
+            if site is None:
+                site = "map.feature"                   # the only bare F.dropout call on the path (mgcvae.py:291-293)
+            if not training or p == 0.0:
+                return input
+            if site in drawn:
+                raise RuntimeError(f"dropout site {site} hit twice")
+            keep = torch.rand(input.shape, generator=gen) >= p
+            drawn[site], probs[site] = keep, float(p)
+            return input * keep.to(input.dtype) / (1.0 - p)
+
+        for m in reg.model_dict.values():
+            m.train()
+        real = Fn.dropout
+        Fn.dropout = fake_dropout
+        try:
+            loss, _ = model.train_loss(inputs=x, inputs_st=x_st, inputs_lane=lanes, lane_label=None, lane_t_mask=None,
+                                       labels=y, labels_st=y_st, map=maps, prediction_horizon=ph)
+            loss.backward()
+        finally:
+            Fn.dropout = real
+        out = {"train_loss": np.float32(loss.item())}
+        for site, keep in drawn.items():
+            if site.startswith("dec"):                 # (B, ph, .) -> the engine's step-major (ph, B, .)
+                keep = keep.permute(1, 0, 2)
+            elif site.startswith("enc"):               # (B, T, .) -> rows b*T + t
+                keep = keep.reshape(-1, keep.shape[-1])
+            out["keep::" + site] = keep.contiguous().numpy().astype(np.uint8)
+        for name, mod in reg.model_dict.items():
+            for pn_, p in mod.named_parameters():
+                if p.grad is not None:
+                    out["grad::" + f"{name}.{pn_}"] = p.grad.numpy().copy()
+        meta = {"mode": mode, "autoregressive": ar, "B": B, "ph": ph, "torch": torch.__version__, "probs": probs,
+                "sites": sorted(drawn), "attention_probability_dropout": "off in the reference run (inside SDPA, not injectable)"}
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+        with open(os.path.join(HERE, tag + ".json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print(tag, "train_loss", float(out["train_loss"]), "sites", sorted(drawn))
+
+
 def run_mlp():
     """nn_component.MLP.Mlp stand-alone: regression and classification (nn.Softmax() with dim=None: dim 0 for the 3-D
     input the reference gives it, dim 1 for a 2-D one)."""
@@ -352,13 +444,15 @@ def run_mapcrop():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    what = sys.argv[1:] or ["modes", "nonar", "mlp", "gmm2d", "mapcrop"]
+    what = sys.argv[1:] or ["modes", "nonar", "dropout", "mlp", "gmm2d", "mapcrop"]
     if "modes" in what:
         for tiny in (True, False):
             for mode in ("basic", "map_cnn", "lane_cnn"):
                 run_mode(mode, tiny)
     if "nonar" in what:
         run_nonar()
+    if "dropout" in what:
+        run_dropout()
     if "mlp" in what:
         run_mlp()
     if "gmm2d" in what:

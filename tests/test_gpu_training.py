@@ -14,6 +14,10 @@ from helpers import batch_for, check_post_step, hp_for, load_golden, rel_err, se
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# Full-size (B=128, 6+6 layers) gradients against the reference's fp32 autograd goldens: the north star's 1e-4.  Rounds
+# 1-2 accepted 1e-3 on norms and 5e-4 on the element-wise heads; test_full_size_gradients_against_the_fp64_oracle (round 3) measures
+# both sides against the fp64 oracle -- HIP 5.1e-6, the reference's fp32 autograd 6.2e-7 (RMS floor) -- so 1e-4 holds with room.
+FULL_TOL = 1e-4
 
 
 class _Env:
@@ -354,9 +358,9 @@ def test_map_cnn_step_matches_reference(tiny):
             assert rel_err(g.cpu().numpy(), z["grad::" + name]) <= TOL, name
         else:
             wn = meta["grad_norms"][name]
-            assert abs(float(g.double().norm()) - wn) <= 1e-3 * wn + 1e-9, name
+            assert abs(float(g.double().norm()) - wn) <= FULL_TOL * wn + 1e-9, name
             rms = wn / np.sqrt(g.numel())
-            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= 5e-4, name
+            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= FULL_TOL, name
     for name, mod in reg.model_dict.items():
         for pn, p in mod.named_parameters():
             key = f"{name}.{pn}"
@@ -415,7 +419,7 @@ def test_map_vit_step_matches_cpu_restatement_autograd(tiny):
     assert len(vit_names) == 4 + 2 + (2 if tiny else 6) * 11 + 2
     for name, g in eng.grad_by_name.items():
         w = want[name].numpy()
-        assert rel_err(g.cpu().numpy(), w) <= (TOL if tiny else 5e-4), name
+        assert rel_err(g.cpu().numpy(), w) <= (TOL if tiny else FULL_TOL), name
 
 
 @pytest.mark.parametrize("tiny", [True, False])
@@ -440,9 +444,9 @@ def test_lane_cnn_step_matches_reference(tiny):
             assert rel_err(g.cpu().numpy(), z["grad::" + name]) <= TOL, name
         else:
             wn = meta["grad_norms"][name]
-            assert abs(float(g.double().norm()) - wn) <= 1e-3 * wn + 1e-9, name
+            assert abs(float(g.double().norm()) - wn) <= FULL_TOL * wn + 1e-9, name
             rms = wn / np.sqrt(g.numel())
-            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= 5e-4, name
+            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= FULL_TOL, name
     for name, mod in reg.model_dict.items():
         for pn, p in mod.named_parameters():
             key = f"{name}.{pn}"
@@ -473,11 +477,11 @@ def test_full_config_step_matches_reference_gradient_norms():
     for name, g in tr.engine.grad_by_name.items():
         want = meta["grad_norms"][name]
         got = float(g.double().norm())
-        assert abs(got - want) <= 1e-3 * want + 1e-9, (name, got, want)
+        assert abs(got - want) <= FULL_TOL * want + 1e-9, (name, got, want)
         # element-wise on the first 256 elements of every gradient; floor = the tensor's RMS from its golden norm
         head = z["gradhead::" + name]
         rms = want / np.sqrt(g.numel())
-        assert rel_err(g.reshape(-1)[:256].cpu().numpy(), head, floor=rms + 1e-30) <= 5e-4, name
+        assert rel_err(g.reshape(-1)[:256].cpu().numpy(), head, floor=rms + 1e-30) <= FULL_TOL, name
     for name, mod in reg.model_dict.items():
         for pn, p in mod.named_parameters():
             key = f"{name}.{pn}"
@@ -491,25 +495,27 @@ def test_full_config_step_matches_reference_gradient_norms():
         assert abs(after[name]["abs_sum"] - c["abs_sum"]) <= 1e-5 * c["abs_sum"], name
 
 
-def test_full_size_gradients_against_the_fp64_oracle(capsys):
+@pytest.mark.parametrize("mode", ["basic", "lane_cnn"])
+def test_full_size_gradients_against_the_fp64_oracle(capsys, mode):
     """Whose error is the full-size gradient gap?  B=128, T=9, ph=12, 6+6 layers, dropout off: the fp64 autograd
     of the reference-form oracle (stock torch.nn modules in double precision, full recompute per AR step) is the arbiter; the
     HIP step's gradients AND the reference's own fp32 autograd (golden ``gradhead::*``, first 256 elements of every gradient,
     written by tests/golden/make_golden.py from the real reference) are both measured against it, per-output relative error
     with the tensor's RMS as the floor.  The HIP step must be within 1e-4 of fp64 on every gradient; the golden-vs-fp64 figure
-    is printed beside it and is what the 5e-4 of test_full_config_step_matches_reference_gradient_norms has to absorb."""
+    is printed beside it: together they bound what test_full_config_step_matches_reference_gradient_norms (FULL_TOL) can see."""
     from multimodal_transformer_amd import training
+    from multimodal_transformer_amd.weights import apply_recipe
     from oracle.reference_form import ReferenceFormModel
     dev = _dev()
-    z, meta = load_golden("full_basic")
-    hp, B, ph = hp_for("basic", False)
+    z, meta = load_golden("full_" + mode)
+    hp, B, ph = hp_for(mode, False)
     hp["autoregressive"] = True
     model, reg = _model(hp, dev)
     set_weights(reg.model_dict, False, z)
-    batch = batch_for("basic", False)
+    batch = batch_for(mode, False)
     c = {k: torch.from_numpy(v) for k, v in batch.items()}
     eng = training.TrainEngine(model, B, c["x_st"].shape[1], ph, dropout=False)
-    eng.set_batch(c["x_st"].to(dev), c["y_st"].to(dev))
+    eng.set_batch(c["x_st"].to(dev), c["y_st"].to(dev), lanes=c["lanes"].to(dev) if "lanes" in c else None)
     loss = float(eng.forward())
     eng.backward()
     torch.cuda.synchronize()
@@ -522,7 +528,8 @@ def test_full_size_gradients_against_the_fp64_oracle(capsys):
             m.p = 0.0
         if isinstance(m, torch.nn.MultiheadAttention):
             m.dropout = 0.0
-    want_loss = ref.train_loss(c["x"].double(), c["x_st"].double(), c["y"].double(), c["y_st"].double(), None, None, ph)
+    want_loss = ref.train_loss(c["x"].double(), c["x_st"].double(), c["y"].double(), c["y_st"].double(),
+                               c["lanes"].double() if "lanes" in c else None, None, ph)
     want_loss.backward()
     want = {f"{k}.{pn}": p.grad for k, mod in ref.m.items() for pn, p in mod.named_parameters() if p.grad is not None}
     assert set(eng.grad_by_name) == set(want)
@@ -538,7 +545,7 @@ def test_full_size_gradients_against_the_fp64_oracle(capsys):
         worst_hip = max(worst_hip, (e_hip, name))
         worst_gold = max(worst_gold, (e_gold, name + f" (HIP on the same 256 elements: {e_hip_head:.2e})"))
     with capsys.disabled():
-        print(f"\nfull-size gradients vs the fp64 oracle (RMS floor): HIP worst {worst_hip[0]:.3e} at {worst_hip[1]}; "
+        print(f"\nfull-size {mode} gradients vs the fp64 oracle (RMS floor): HIP worst {worst_hip[0]:.3e} at {worst_hip[1]}; "
               f"reference fp32 autograd (golden heads) worst {worst_gold[0]:.3e} at {worst_gold[1]}")
     assert worst_hip[0] <= 1e-4, worst_hip
 
@@ -842,3 +849,55 @@ def test_a_step_whose_decode_gave_up_leaves_the_weights_alone():
     assert any(not torch.equal(p.detach(), q) for (_, p), q in zip(tr.engine.named_params, before))
     ops.decoder_status()
     lib.mmt_debug_decoder_stall(0)        # re-arm the one-launch forms for the tests that follow (the status query switched them off)
+
+
+def _sweep_buffers(eng):
+    S, ht = eng.s, eng.head_tape
+    out = {"G": S.G, "gho": ht.gin, "ghz": ht.ghz[0], "ghum": ht.ghum[0]}
+    for l in range(eng.Ld - 1, -1, -1):
+        out.update({f"gx[{l + 1}]": S.gx[l + 1], f"gf2[{l}]": S.gf2m[l], f"gf1[{l}]": S.gf1[l], f"gx2[{l}]": S.gx2[l], f"go2[{l}]": S.go2m[l],
+                    f"gcq[{l}]": S.gcq[l], f"gmkv[{l}]": S.gmkv[l], f"gx1[{l}]": S.gx1[l], f"go1[{l}]": S.go1m[l], f"gqkv[{l}]": S.gqkv[l]})
+    out["gx[0]"] = S.gx[0]
+    return {k: v.detach().clone() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("mode,B", [("basic", 128), ("basic", 37), ("lane_cnn", 64), ("basic", 200)])
+def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B):
+    """The reverse-time sweep as ONE weight-stationary pipeline launch (csrc/decoder_bwd_pipe.cuh) against the
+    chain of row-block kernels it replaces: every buffer the deferred weight-gradient GEMMs read, in sweep order (the first one that
+    differs names the stage), then loss and every gradient.  Different summation trees and 2 tag bits per hand-off through
+    ph x (3L + 1) hops: 1e-4 (observed 3e-5 on the intermediate buffers)."""
+    from multimodal_transformer_amd import ops, training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _dev()
+    b = make_batch(B, 8, 12, seed=11, with_lanes=(mode == "lane_cnn"))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    res = []
+    for pipe in (False, True):
+        hp = make_hyperparams(mode, history=8, horizon=12)
+        model, reg = _model(hp, dev)
+        apply_recipe(reg.model_dict, seed=4)
+        eng = training.TrainEngine(model, B, 9, 12, dropout=False)
+        eng.sweep_pipeline = pipe
+        eng.set_batch(t["x_st"], t["y_st"], lanes=t.get("lanes"))
+        loss = float(eng.forward())
+        eng.backward()
+        torch.cuda.synchronize()
+        ops.decoder_status()
+        assert (eng._sweep_pipe() is not None) == pipe, eng.sweep_pipe_why
+        res.append((loss, _sweep_buffers(eng), eng.flat_grad.clone(), {k: v.clone() for k, v in eng.grad_by_name.items()}))
+    assert res[0][0] == res[1][0]
+    worst = (0.0, None)
+    for name in res[0][1]:
+        want, got = res[0][1][name].cpu().numpy(), res[1][1][name].cpu().numpy()
+        assert np.isfinite(got).all(), name
+        e = rel_err(got, want)
+        worst = max(worst, (e, name))
+        assert e <= 1e-4, (name, e)
+    for name, g in res[1][3].items():
+        e = rel_err(g.cpu().numpy(), res[0][3][name].cpu().numpy())
+        worst = max(worst, (e, name))
+        assert e <= 1e-4, (name, e)
+    print("pipeline sweep vs launch-per-kernel sweep: worst relative error", worst)
