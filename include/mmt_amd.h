@@ -300,7 +300,8 @@ int mmt_decoder_last_path(void);
  * disabled on this device, so re-issuing the call runs launch-per-phase).  Callers check it where they synchronise anyway
  * (the reference copies every prediction to the host, trajectron.py:216-221).  No counterpart in the reference. */
 int mmt_decoder_status(void *stream);
-/* test hook: the next one-launch decodes lose one workgroup (their waits must time out); 0 re-arms.  Not for production. */
+/* test hook: bit 0 - the next one-launch decodes lose one workgroup (their waits must time out); bit 1 - the next one-launch
+ * backward sweeps (mmt_sweep_pipe_run) do; 0 re-arms.  Not for production. */
 int mmt_debug_decoder_stall(int on);
 int mmt_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
                         const float *start_pos, const float *map_feat, int map_dim,

@@ -2670,7 +2670,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         f.head_bias = last.ff2.b;
         f.head_ln = last.ln3;
         f.nlayers = L;
-        f.test_stall = g_test_stall.load(std::memory_order_relaxed);
+        f.test_stall = g_test_stall.load(std::memory_order_relaxed) & 1;
         f.R = pg.R;
         f.NHW = pg.NHW;
         f.NC = NC;
@@ -2694,7 +2694,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         f.memkv = memkv;
         f.sync = sync;
         f.nlayers = L;
-        f.test_stall = g_test_stall.load(std::memory_order_relaxed);
+        f.test_stall = g_test_stall.load(std::memory_order_relaxed) & 1;
         hipLaunchKernelGGL((mmt_dec_fused4_kernel<DH, CPW>), grid, blk, lds_a, st, f);
         p = 3 * L * ph;
       }
@@ -2795,13 +2795,18 @@ extern "C" int mmt_decoder_status(void *stream) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_decoder_fault_info), zero4, sizeof(zero4));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_decoder_fault), &zero, sizeof(zero));
   g_dev[cur_dev()].fused_disabled.store(true, std::memory_order_relaxed);
+  if (v & 4u)
+    return mmt_set_error(MMT_ELAUNCH, "mmt_sweep_pipe_run: the one-launch backward sweep on this device gave up waiting for a stage "
+                                      "(GPU shared or CU-masked?); that step's loss is NaN and its gradients are undefined.  The "
+                                      "one-launch forms are now disabled on this device: the next step runs the launch-per-kernel "
+                                      "sweep [first give-up: workgroup %u phase %u cluster %u]", info[1], info[2], info[3]);
   return mmt_set_error(MMT_ELAUNCH, "mmt_decoder_forward: a one-launch decode on this device gave up waiting for a workgroup of "
                                     "its cluster (GPU shared or CU-masked?); that call's outputs are NaN.  The one-launch form is "
                                     "now disabled on this device: re-issue the call (it runs launch-per-phase) [first give-up: "
                                     "workgroup %u phase %u cluster %u]", info[1], info[2], info[3]);
 }
 extern "C" int mmt_debug_decoder_stall(int on) {
-  g_test_stall.store(on ? 1 : 0, std::memory_order_relaxed);
+  g_test_stall.store(on & 3, std::memory_order_relaxed);      // bit 0: the one-launch decoder forms, bit 1: the backward sweep pipeline
   if (!on) g_dev[cur_dev()].fused_disabled.store(false, std::memory_order_relaxed);   // tests re-arm the one-launch form
   return MMT_OK;
 }
@@ -2995,7 +3000,7 @@ extern "C" int mmt_sweep_pipe_run(const mmt_sweep_pipe *a, float *ws, void *stre
   f.x0buf = p;
   p += NC * 4 * d;
   f.NC = (int)NC, f.R = pg.R, f.NHW = pg.NHW;
-  f.test_stall = g_test_stall.load(std::memory_order_relaxed);
+  f.test_stall = (g_test_stall.load(std::memory_order_relaxed) >> 1) & 1;
   // every hand-off word starts as the 0xFFFFFFFF no tag matches; the time-out word as 0
   hipLaunchKernelGGL(mmt_bwd_pipe_fill_kernel, dim3(512), dim3(256), 0, st, ws, (size_t)(p - (ws + 64)) / 4);
   CL_CHECK("mmt_bwd_pipe_fill_kernel");
