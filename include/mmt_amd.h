@@ -358,8 +358,8 @@ int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *memory, con
 /* ---- reverse-time sweep of the training step as ONE weight-stationary pipeline launch (round 3) -----------------------------
  * Replaces the per-(step, layer) kernel chain of the decoder backward (the autograd of train.py:248 `loss.backward()` through
  * mgcvae.py:432-446's position feedback; training.TrainEngine._sweep here): same inputs (the forward stash), same outputs (every
- * gradient buffer the deferred weight-gradient GEMMs read), dropout-free graph, autoregressive decode, decoder/MLP head with one
- * hidden layer (Basic / Lane configurations).  No counterpart in the reference (which calls autograd).
+ * gradient buffer the deferred weight-gradient GEMMs read), with or without the training-mode keep masks, autoregressive decode,
+ * decoder/MLP head with one hidden layer (Basic / Lane configurations).  No counterpart in the reference (which calls autograd).
  * Stage kinds index the [3] arrays: 0 = feed forward (LayerNorm3), 1 = cross attention (LayerNorm2), 2 = self attention
  * (LayerNorm1).  w1 / w2 / w2k / w2v / w_ofc are 4x4x1-order packs (mmt_pack_jobs kinds 2 / 3 with tr = 1: the sweep multiplies
  * by W where the forward multiplies by W^T):
@@ -382,6 +382,11 @@ typedef struct {
   float *gcq, *gmkv;
   const float *qkv, *p1;                  /* self attention: q|k|v (ph,B,3d), probabilities */
   float *gqkv;
+  /* training-mode dropout (NULL: that site is not dropped), keep bytes laid out like the tensors they mask: k_ln[kind] = dropout3 /
+   * dropout2 / dropout1 (ph,B,d); k_ff = the feed-forward hidden units (ph,B,d_ff; the f1 stash is already dropped);
+   * k_att[0] = cross-attention probabilities (B,H,ph,T), k_att[1] = self-attention probabilities (B,H,ph,ph); s_* = 1/(1-p) */
+  const uint8_t *k_ln[3], *k_ff, *k_att[2];
+  float s_ln[3], s_ff, s_att[2];
 } mmt_sweep_layer;
 typedef struct {
   int32_t B, T, ph, d, H, nlayers, d_ff, n_out, n_pos, pad_;
@@ -394,6 +399,8 @@ typedef struct {
   const float *h_hu, *h_xhat, *h_rstd;    /* head tape: relu(LN(.)) (ph,B,n_out), xhat, rstd (ph,B) */
   float *h_ghum, *h_ghz, *h_gho;          /* out: masked dy of the head's LayerNorm, its dx, gradient at output_fc's output */
   float *poison;                          /* 1 float: NaN when the sweep gave up (the step's loss / optimizer guard), may be NULL */
+  const uint8_t *k_pe;                    /* PositionalEncoding.dropout keep bytes (ph,B,d) or NULL */
+  float s_pe, pad2_;
 } mmt_sweep_pipe;
 int mmt_sweep_pipe_supported(const mmt_sweep_pipe *args);
 size_t mmt_sweep_pipe_workspace_floats(const mmt_sweep_pipe *args);

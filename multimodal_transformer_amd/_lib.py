@@ -115,14 +115,17 @@ class PackJob(C.Structure):
 class SweepLayer(C.Structure):
     _fields_ = [("w1", fptr * 3), ("w2", fptr * 3), ("w2k", fptr), ("w2v", fptr), ("gamma", fptr * 3), ("xhat", fptr * 3),
                 ("rstd", fptr * 3), ("gdy", fptr * 3), ("gdx", fptr * 3), ("f1", fptr), ("gf1", fptr), ("cq", fptr), ("mkv", fptr),
-                ("p2", fptr), ("gcq", fptr), ("gmkv", fptr), ("qkv", fptr), ("p1", fptr), ("gqkv", fptr)]
+                ("p2", fptr), ("gcq", fptr), ("gmkv", fptr), ("qkv", fptr), ("p1", fptr), ("gqkv", fptr),
+                ("k_ln", fptr * 3), ("k_ff", fptr), ("k_att", fptr * 2), ("s_ln", C.c_float * 3), ("s_ff", C.c_float),
+                ("s_att", C.c_float * 2)]
 
 
 class SweepPipe(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "T", "ph", "d", "H", "nlayers", "d_ff", "n_out", "n_pos", "pad_")] + \
                [("layer", SweepLayer * MMT_MAX_LAYERS)] + \
                [(n, fptr) for n in ("G", "gx0", "w_in", "w_hout", "h_gamma", "w_h0", "w_ofc", "h_hu", "h_xhat", "h_rstd", "h_ghum",
-                                    "h_ghz", "h_gho", "poison")]
+                                    "h_ghz", "h_gho", "poison", "k_pe")] + \
+               [("s_pe", C.c_float), ("pad2_", C.c_float)]
 
 
 class LnGradJob(C.Structure):

@@ -21,8 +21,10 @@
 // tape): the same buffers TrainEngine._sweep fills.  Phase p' = s' (3L) + k' with s' = ph - 1 - s and k' = 3 (L - 1 - layer) +
 // {C': 0, B': 1, A': 2}; hand-off slots, tags and time-outs are those of the forward pipeline.
 //
-// Dropout-free graph, Basic / Lane configurations (the head chain is decoder/MLP with one hidden layer); anything else stays on
-// the launch-per-kernel sweep (mmt_sweep_pipe_supported).
+// Basic / Lane configurations (the head chain is decoder/MLP with one hidden layer); anything else stays on the launch-per-kernel
+// sweep (mmt_sweep_pipe_supported).  Training-mode dropout: the DROP instantiation reads the step's keep bytes (requested before a
+// visit's poll) where the reference's modules drop -- dropout1/2/3 (the sub-layer branch sees keep * scale * dx, the residual dx),
+// the feed-forward hidden units, the attention probabilities, the positional encoding.
 
 constexpr int BK_C = 0, BK_B = 1, BK_A = 2;
 
@@ -129,9 +131,11 @@ __device__ __forceinline__ void bwd_row_issue(BwdRow &X, const float *xhat_s, co
 }
 // dy = residual + parts (fixed order); dx = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)); dx -> xs row, tagged residual row for the
 // next stage and the two stash rows (write: slice 0 of the stage)
+// keep_scale > 0 (training-mode dropout on the sub-layer's output, dropout1/2/3): the sub-layer branch sees dxm = keep * scale * dx
+// (xs row and the dx stash row, which feeds the weight gradients); the residual path keeps dx
 __device__ __forceinline__ void bwd_ln_finish(const Red4Regs &R, const BwdRow &X, const f32x4 &gam, float *xs_row, bool write,
                                               float *xres_out_row, unsigned tag_out, float *gdy_row, float *gdx_row, bool in_batch,
-                                              int d) {
+                                              int d, unsigned keep = 0u, float keep_scale = 0.f) {
   const int q = lane_id();
   const bool live = q < (d >> 2);
   f32x4 dy = R.res;
@@ -145,13 +149,15 @@ __device__ __forceinline__ void bwd_ln_finish(const Red4Regs &R, const BwdRow &X
   const float m2 = wave64_total((gg[0] * X.xhat[0] + gg[1] * X.xhat[1]) + (gg[2] * X.xhat[2] + gg[3] * X.xhat[3])) * inv_d;
 #pragma unroll
   for (int e = 0; e < 4; ++e) dx[e] = X.rstd * (gg[e] - m1 - X.xhat[e] * m2);
+  f32x4 dxm = dx;
+  if (keep_scale > 0.f) dxm = dx * keep4w(keep, keep_scale);
   if (live) {
-    *reinterpret_cast<f32x4 *>(xs_row + 4 * q) = dx;
+    *reinterpret_cast<f32x4 *>(xs_row + 4 * q) = dxm;
     if (write) {
       bs4x<AUX_SC1>(mk_rsrc(xres_out_row), (unsigned)q * 16u, tag4(dx, tag_out));
       if (in_batch) {
         *reinterpret_cast<f32x4 *>(gdy_row + 4 * q) = dy;
-        *reinterpret_cast<f32x4 *>(gdx_row + 4 * q) = dx;
+        *reinterpret_cast<f32x4 *>(gdx_row + 4 * q) = dxm;
       }
     }
   }
@@ -207,9 +213,11 @@ __device__ __forceinline__ void bwd_weights_issue(MainRegs4<DH, PHASE> &M, const
 // ---- one-query attention backward of one head for the 4 agents of a cluster, on ONE wave: lane = (agent ar, key j) -------------
 // in : dO rows (do_ + ar * ldo), K / V staging tiles (rows beyond the keys are zeros), P = this lane's probability (0 beyond the keys)
 // out: ps[lane] = scale * dS, pp[lane] = P, dq rows (dq + ar * ldq)
+// att_scale > 0 (dropout on the probabilities): the forward used keep * att_scale * P, so dP = keep * att_scale * (dO . V_j) and
+// the value gradient takes the dropped probability (pp)
 template <int DH>
 __device__ __forceinline__ void attend4_bwd(int na, int nkeys, float P, const float *do_, int ldo, const float *Ks, const float *Vs,
-                                            float *ps, float *pp, float *dq, int ldq) {
+                                            float *ps, float *pp, float *dq, int ldq, unsigned att_keep = 1u, float att_scale = 0.f) {
   constexpr int LDK = DH + 4, DPL = DH / 16;
   const int lane = lane_id(), ar = lane >> 4, l16 = lane & 15;
   const bool valid = ar < na && l16 < nkeys;
@@ -226,10 +234,16 @@ __device__ __forceinline__ void attend4_bwd(int na, int nkeys, float P, const fl
     }
   }
   const float Pv = valid ? P : 0.f;
+  float Pd = Pv;                                   // the probability the forward multiplied the value by
+  if (att_scale > 0.f) {
+    const float kf = (att_keep & 0xffu) ? att_scale : 0.f;
+    dP *= kf;
+    Pd = Pv * kf;
+  }
   const float sum = row16_sum(Pv * dP);
   const float ds = Pv * (dP - sum) * (1.0f / sqrtf((float)DH));
   ps[lane] = ds;
-  pp[lane] = Pv;
+  pp[lane] = Pd;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -255,7 +269,7 @@ __device__ __forceinline__ void attend4_bwd(int na, int nkeys, float P, const fl
 
 // ---- stages -------------------------------------------------------------------------------------------------------------------
 // Stage kind KIND of `layer`, slices / heads g0 .. g0 + NH - 1, replica `replica`.
-template <int DH, int KIND, int NH, int D, int FS>
+template <int DH, int KIND, int NH, int D, int FS, bool DROP>
 __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g0, int replica, const BwdLds &S, const PipeSync &ps) {
   constexpr int PHASE = KIND == BK_C ? PH_C : PH_B;          // register-tile geometry of the linears
   constexpr int NM = KIND == BK_A ? 3 : NH;                  // A': one head, three second linears (q | k | v rows of in_proj)
@@ -300,6 +314,25 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
       // ---- 0. everything that does not depend on the previous phase: requested before the poll
       BwdRow X;
       if (red_wave) bwd_row_issue(X, W.xhat[KIND] + srow * d, W.rstd[KIND] + srow, a0 + wv, B, d);
+      unsigned k_ln = 0u, k_att = 1u;
+      float s_ln = 0.f, s_ff = 1.f, s_att = 0.f;
+      if constexpr (DROP) {      // this visit's keep bytes: requested before the poll like everything else that is not handed over
+        const uint8_t *kl = W.k_ln[KIND];
+        if (kl) s_ln = W.s_ln[KIND];
+        if (red_wave) k_ln = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(kl), (kl && lane < (d >> 2) && a0 + wv < B)
+                                                                    ? (unsigned)((srow + a0 + wv) * d + 4 * lane) : OOB, 0, 0);
+        if constexpr (KIND == BK_C) {
+          if (W.k_ff) s_ff = W.s_ff;
+        } else {
+          const uint8_t *ka = W.k_att[KIND == BK_B ? 0 : 1];
+          if (ka) {
+            s_att = W.s_att[KIND == BK_B ? 0 : 1];
+            const int ar = lane >> 4, l16 = lane & 15, Lk = KIND == BK_B ? T : ph, nk = KIND == BK_B ? T : s + 1;
+            k_att = __builtin_amdgcn_raw_buffer_load_b8(mk_rsrc(ka), (wv < NH && ar < na && l16 < nk)
+                                                            ? (unsigned)((((a0 + ar) * H + g0 + wv) * ph + s) * Lk + l16) : OOB, 0, 0);
+          }
+        }
+      }
       float f1v = 0.f;
       f32x4 kvr[NH][DH / 16], oldr[NH][DH / 16], qr = (f32x4){0.f, 0.f, 0.f, 0.f};
       float Pl = 0.f;
@@ -354,7 +387,7 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
       if (red_wave) {
         const size_t ro = (srow + a0 + wv) * d;
         bwd_ln_finish(R, X, gam, S.xs + wv * ldx, g0 == 0, xres_out + ((size_t)m * 16 + wv) * d, tag_out, W.gdy[KIND] + ro, W.gdx[KIND] + ro,
-                      a0 + wv < B, d);
+                      a0 + wv < B, d, k_ln, s_ln);
       }
       if constexpr (KIND != BK_C) {
 #pragma unroll
@@ -377,7 +410,9 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
         const int b = lane >> 2, j = lane & 3, r = b >> 2, bb = b & 3;
         if (bb < cgw) {
           const int col = (wv * cgw + bb) * 4 + j;
-          const float v = f1v > 0.f ? tot : 0.f;              // relu'(hidden) (rows beyond the batch: f1v = 0)
+          // relu'(hidden) (rows beyond the batch: f1v = 0); with dropout on the hidden units the stash holds keep * scale * relu(.),
+          // whose derivative is scale where it is positive
+          const float v = f1v > 0.f ? (DROP ? tot * s_ff : tot) : 0.f;
           S.t1[r * LD1 + col] = v;
           if (r < na) W.gf1[(srow + a0 + r) * (size_t)(FS * H) + g0 * FS + col] = v;
         }
@@ -395,7 +430,7 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
         if (wv < NH) {
           const int h = wv;
           attend4_bwd<DH>(na, nkeys, Pl, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
-                          S.pp + h * 64, S.t2 + h * 4 * LD1, LD1);
+                          S.pp + h * 64, S.t2 + h * 4 * LD1, LD1, k_att, s_att);
           // dq -> stash (gcq / the q columns of gqkv): lane (ar, l16) holds DH/16 = 2 consecutive columns
           const int ar = lane >> 4, l16 = lane & 15, g = g0 + h;
           if (ar < na) {
@@ -455,7 +490,7 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
 }
 
 // ---- head workgroups: close step s + 1 (the position feedback) and open step s (decoder/MLP backward, output_fc backward) ------
-template <int DH, int D, int FS>
+template <int DH, int D, int FS, bool DROP>
 __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int jh, const BwdLds &S, const PipeSync &ps) {
   constexpr int LD1 = BW_LD1;
   const mmt_sweep_pipe &A = f.a;
@@ -488,6 +523,12 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
       const int a0 = m * 4, na = min(4, B - a0), ag = a0 + wv;
       const bool mine = red_wave && ag < B;
       // ---- 0. prefetch: the head tape of step s (independent of the previous phase)
+      unsigned k_pe = 0u;
+      if constexpr (DROP) {      // PositionalEncoding's dropout: the gradient at the embedding of step s + 1
+        if (red_wave && sp > 0)
+          k_pe = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(A.k_pe), (A.k_pe && mine && lane < (d >> 2))
+                                                          ? (unsigned)(((s + 1) * B + ag) * d + 4 * lane) : OOB, 0, 0);
+      }
       float huv = 0.f, hxh = 0.f, hrs = 0.f;
       if (red_wave && s >= 0) {
         huv = bl1(mk_rsrc(A.h_hu), (mine && c < NO && lane < 32) ? (unsigned)((s * B + ag) * NO + c) * 4u : OOB);
@@ -509,6 +550,9 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
           f32x4 gx = R.res;
 #pragma unroll
           for (int g = 0; g < 8; ++g) gx += R.p[g];
+          if constexpr (DROP) {
+            if (A.k_pe) gx = gx * keep4w(k_pe, A.s_pe);
+          }
           if (mine && lane < (d >> 2)) *reinterpret_cast<f32x4 *>(A.gx0 + ((size_t)(s + 1) * B + ag) * d + 4 * lane) = gx;
           float t0 = 0.f, t1 = 0.f;
           if (lane < (d >> 2)) {
@@ -568,7 +612,7 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
   }
 }
 
-template <int DH, int D, int FS>
+template <int DH, int D, int FS, bool DROP>
 __global__ __launch_bounds__(CNT) void mmt_bwd_pipe4_kernel(BwdPipeArgs f) {
   extern __shared__ __align__(16) float smem[];
   const BwdLds S = bwd_lds(smem, f.a.d);
@@ -581,11 +625,11 @@ __global__ __launch_bounds__(CNT) void mmt_bwd_pipe4_kernel(BwdPipeArgs f) {
   __syncthreads();
   if (rb < L * per_layer) {
     const int layer = rb / per_layer, q = rb - layer * per_layer;
-    if (q < H) bwd_stage<DH, BK_A, 1, D, FS>(f, layer, q, replica, S, ps);
-    else if (q < H + H / 2) bwd_stage<DH, BK_B, 2, D, FS>(f, layer, 2 * (q - H), replica, S, ps);
-    else bwd_stage<DH, BK_C, 1, D, FS>(f, layer, q - H - H / 2, replica, S, ps);
+    if (q < H) bwd_stage<DH, BK_A, 1, D, FS, DROP>(f, layer, q, replica, S, ps);
+    else if (q < H + H / 2) bwd_stage<DH, BK_B, 2, D, FS, DROP>(f, layer, 2 * (q - H), replica, S, ps);
+    else bwd_stage<DH, BK_C, 1, D, FS, DROP>(f, layer, q - H - H / 2, replica, S, ps);
   } else {
-    bwd_head<DH, D, FS>(f, replica, rb - L * per_layer, S, ps);
+    bwd_head<DH, D, FS, DROP>(f, replica, rb - L * per_layer, S, ps);
   }
 }
 

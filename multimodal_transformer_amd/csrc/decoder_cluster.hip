@@ -2961,6 +2961,14 @@ static bool sweep_pipe_static_ok(const mmt_sweep_pipe *a) {
   if (a->T < 1 || a->T > KMAX || a->ph < 1 || a->ph > KMAX || a->B < 1 || a->B > PIPE_MAX_B) return false;
   return true;
 }
+static bool sweep_has_dropout(const mmt_sweep_pipe *a) {
+  if (a->k_pe) return true;
+  for (int l = 0; l < a->nlayers; ++l) {
+    const mmt_sweep_layer &W = a->layer[l];
+    if (W.k_ln[0] || W.k_ln[1] || W.k_ln[2] || W.k_ff || W.k_att[0] || W.k_att[1]) return true;
+  }
+  return false;
+}
 extern "C" int mmt_sweep_pipe_supported(const mmt_sweep_pipe *a) {
   if (!sweep_pipe_static_ok(a) || dec_env().no_fused || dec_env().no_pipe || getenv("MMT_NO_PIPELINE_SWEEP")) return 0;
   const int dev = cur_dev(), ncu = dev_ncu(dev);
@@ -2969,7 +2977,9 @@ extern "C" int mmt_sweep_pipe_supported(const mmt_sweep_pipe *a) {
   if (pg.R < 1 || pg.grid > ncu) return 0;
   int nb = 0;
   const size_t lds = bwd_lds_floats(a->d) * sizeof(float);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)mmt_bwd_pipe4_kernel<32, 256, 64>, CNT, lds) != hipSuccess) {
+  const bool drop = sweep_has_dropout(a);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, drop ? (const void *)mmt_bwd_pipe4_kernel<32, 256, 64, true>
+                                                         : (const void *)mmt_bwd_pipe4_kernel<32, 256, 64, false>, CNT, lds) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -3005,7 +3015,8 @@ extern "C" int mmt_sweep_pipe_run(const mmt_sweep_pipe *a, float *ws, void *stre
   hipLaunchKernelGGL(mmt_bwd_pipe_fill_kernel, dim3(512), dim3(256), 0, st, ws, (size_t)(p - (ws + 64)) / 4);
   CL_CHECK("mmt_bwd_pipe_fill_kernel");
   const size_t lds = bwd_lds_floats(a->d) * sizeof(float);
-  hipLaunchKernelGGL((mmt_bwd_pipe4_kernel<32, 256, 64>), dim3(pg.grid), dim3(CNT), lds, st, f);
+  if (sweep_has_dropout(a)) hipLaunchKernelGGL((mmt_bwd_pipe4_kernel<32, 256, 64, true>), dim3(pg.grid), dim3(CNT), lds, st, f);
+  else hipLaunchKernelGGL((mmt_bwd_pipe4_kernel<32, 256, 64, false>), dim3(pg.grid), dim3(CNT), lds, st, f);
   CL_CHECK("mmt_bwd_pipe4_kernel");
   hipLaunchKernelGGL(mmt_bwd_pipe_check_kernel, dim3(1), dim3(64), 0, st, (const unsigned *)f.sync, a->poison);
   CL_CHECK("mmt_bwd_pipe_check_kernel");

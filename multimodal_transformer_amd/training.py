@@ -1033,15 +1033,16 @@ class TrainEngine:
     sweep_pipeline = True          # False: always the launch-per-kernel sweep (tests compare the two)
 
     def _sweep_pipe(self):
-        """The descriptor of the one-launch sweep (csrc/decoder_bwd_pipe.cuh), or None where it does not apply: dropout-free
-        autoregressive graph, Basic / Lane configuration, the shipped decoder geometry, decoder/MLP with one hidden layer."""
+        """The descriptor of the one-launch sweep (csrc/decoder_bwd_pipe.cuh), or None where it does not apply: autoregressive
+        graph (with or without dropout), Basic / Lane configuration, the shipped decoder geometry, decoder/MLP with one hidden
+        layer."""
         sp = self.__dict__.get("_sweep_pipe_state")
         if sp is not None:
             return sp or None
         self._sweep_pipe_state = False
         dev = torch.device(self.device)
         self.sweep_pipe_why = "configuration (device / teacher forcing / map mode / dropout / head depth)"
-        if (dev.type != "cuda" or not self.sweep_pipeline or self.teacher_forced or self.map_mode or self.drop.active
+        if (dev.type != "cuda" or not self.sweep_pipeline or self.teacher_forced or self.map_mode
                 or len(self.head_tape.hidden) != 1):
             return None
         from . import _lib
@@ -1090,11 +1091,23 @@ class TrainEngine:
             Wl.f1, Wl.gf1 = P(S.f1[l]), P(S.gf1[l])
             Wl.cq, Wl.mkv, Wl.p2, Wl.gcq, Wl.gmkv = P(S.cq[l]), P(S.mkv[l]), P(S.p2[l]), P(S.gcq[l]), P(S.gmkv[l])
             Wl.qkv, Wl.p1, Wl.gqkv = P(S.qkv[l]), P(S.p1[l]), P(S.gqkv[l])
+            # training-mode dropout: the step's keep bytes where the reference's modules drop (None: that site is not dropped)
+            D = self.drop.get
+            for k, site in enumerate((f"dec{l}.drop3", f"dec{l}.drop2", f"dec{l}.drop1")):
+                if D(site) is not None:
+                    Wl.k_ln[k], Wl.s_ln[k] = P(D(site)[0]), D(site)[1]
+            if D(f"dec{l}.ff") is not None:
+                Wl.k_ff, Wl.s_ff = P(D(f"dec{l}.ff")[0]), D(f"dec{l}.ff")[1]
+            for k, site in enumerate((f"dec{l}.attn2", f"dec{l}.attn1")):
+                if D(site) is not None:
+                    Wl.k_att[k], Wl.s_att[k] = P(D(site)[0]), D(site)[1]
         ht = self.head_tape
         A.G, A.gx0, A.w_in = P(S.G), P(S.gx[0]), P(dec.input_fc.weight)
         A.w_hout, A.h_gamma, A.w_h0, A.w_ofc = P(out.weight), P(ln0.weight), P(lin0.weight), ofc[0]
         A.h_hu, A.h_xhat, A.h_rstd = P(ht.hu[0]), P(ht.hxhat[0]), P(ht.hrstd[0])
         A.h_ghum, A.h_ghz, A.h_gho, A.poison = P(ht.ghum[0]), P(ht.ghz[0]), P(ht.gin), P(self.loss)
+        if self.drop.get("dec.pe") is not None:
+            A.k_pe, A.s_pe = P(self.drop.get("dec.pe")[0]), self.drop.get("dec.pe")[1]
         self.sweep_pipe_why = "mmt_sweep_pipe_supported (device fit / disabled)"
         if not lib.mmt_sweep_pipe_supported(C.byref(A)):
             return None

@@ -921,8 +921,9 @@ def _sweep_buffers(eng):
     return {k: v.detach().clone() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("mode,B", [("basic", 128), ("basic", 37), ("lane_cnn", 64), ("basic", 200)])
-def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B):
+@pytest.mark.parametrize("mode,B,dropout", [("basic", 128, False), ("basic", 37, False), ("lane_cnn", 64, False), ("basic", 200, False),
+                                             ("basic", 128, True), ("lane_cnn", 29, True)])
+def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B, dropout):
     """The reverse-time sweep as ONE weight-stationary pipeline launch (csrc/decoder_bwd_pipe.cuh) against the
     chain of row-block kernels it replaces: every buffer the deferred weight-gradient GEMMs read, in sweep order (the first one that
     differs names the stage), then loss and every gradient.  Different summation trees and 2 tag bits per hand-off through
@@ -937,9 +938,16 @@ def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B):
     res = []
     for pipe in (False, True):
         hp = make_hyperparams(mode, history=8, horizon=12)
-        model, reg = _model(hp, dev)
+        if dropout:      # the modules' own probabilities (0.2), same seed: both engines draw the same masks
+            from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+            hp["autoregressive"] = True
+            reg = ModelRegistrar("/tmp", dev)
+            model = MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, [])
+        else:
+            model, reg = _model(hp, dev)
         apply_recipe(reg.model_dict, seed=4)
-        eng = training.TrainEngine(model, B, 9, 12, dropout=False)
+        eng = training.TrainEngine(model, B, 9, 12, dropout=None if dropout else False, seed=5)
+        assert eng.drop.active == dropout
         eng.sweep_pipeline = pipe
         eng.set_batch(t["x_st"], t["y_st"], lanes=t.get("lanes"))
         loss = float(eng.forward())
