@@ -7,9 +7,9 @@
 // loss.backward()) is inherently sequential -- ph x (3L + 1) dependent hops -- so, as in the forward, a workgroup is bound for
 // the whole sweep to one (layer, sub-layer, slice), keeps the weights of ITS slice of dX = dY W in registers, and the 4-agent
 // clusters flow through the stages in reverse layer and reverse time order:
-//   stage C' (feed forward, slice g of H):   dy = sum of the parts + residual;  gf2 = LayerNorm3 backward(dy);
+//   stage C' (feed forward, 2 slices of H):  dy = sum of the parts + residual;  gf2 = LayerNorm3 backward(dy);
 //                                            gf1[:, slice] = relu'(f1) * (gf2 W2[:, slice]);  part = gf1[:, slice] W1[slice, :]
-//   stage B' (cross attention, 2 heads):     go2 = LayerNorm2 backward;  dO_h = go2 Wo[:, head];  one-query attention backward
+//   stage B' (cross attention, head g):      go2 = LayerNorm2 backward;  dO_h = go2 Wo[:, head];  one-query attention backward
 //                                            (dq -> gcq, dK / dV of the memory accumulated by this workgroup, which owns the head);
 //                                            part = dq_h Wq[head, :]
 //   stage A' (self attention, head g):       go1 = LayerNorm1 backward;  dO_h = go1 Wo[:, head];  attention backward over the keys
@@ -41,6 +41,7 @@ struct BwdLds {
 };
 constexpr int BW_LD1 = 3 * 32 + 8;             // row stride of t1 / t2 (<= 96 columns)
 constexpr int BW_LDQ = 32 + 4;
+constexpr int BW_MAXPOS = 2 * 4 * BW_LDQ / 8;  // clusters whose running position gradient a head workgroup keeps in LDS (its qs tile)
 __host__ __device__ __forceinline__ size_t bwd_lds_floats(int d) {
   return (size_t)4 * (d + MMT_PAD) + 2 * 4 * BW_LD1 + 2 * 4 * BW_LD1 + 2 * 4 * BW_LDQ + 128 + 128 + 64 + 2 * (2 * 4 * KMAX * (32 + 4));
 }
@@ -58,37 +59,67 @@ __device__ __forceinline__ BwdLds bwd_lds(float *smem, int d) {
   return L;
 }
 
+#ifndef BW_PROBES
+#define BW_PROBES 3
+#endif
+#ifndef BW_PROBE_SLEEP
+#define BW_PROBE_SLEEP 3
+#endif
 // slot of phase q (as the forward pipeline: 2 buffers x 4 row blocks of the 16-row cluster slots)
 __device__ __forceinline__ size_t bwd_rowblock(unsigned q, int d) { return (size_t)4 * ((q >> 1) & 3u) * d; }
 
 // ---- hand-off: poll the previous phase's rows until every word carries its tag (poll_rows without the ClArgs block) ------------
 // X0: one full row from x0buf (the head's gx[L][s]); else residual row + the parts at stride GS
+// the loads of one full attempt
 template <bool X0, int GS>
+__device__ __forceinline__ void bwd_poll_issue(Red4Regs &R, const float *res_base, const float *part_base, int d, int H) {
+  const int row = wave_id(), q = lane_id();
+  // parts of a cluster: [16 rows][H][d] -- the H parts of a row are 4 H d contiguous bytes (with [H][16][d] the 8 loads of a lane
+  // were 16 KB apart: a 9-row fetch took 3.2 us where a 5-row one took 1.4)
+  const unsigned co = q < (d >> 2) ? (unsigned)q * 16u : OOB, gstride = (unsigned)d * 4u;
+  R.res = bl4x<AUX_SC1>(mk_rsrc(res_base + (size_t)row * d), co);
+  if constexpr (!X0) {
+    const rsrc_t pp = mk_rsrc(part_base + (size_t)row * H * d);
+#pragma unroll
+    for (int g = 0; g < 8 / GS; ++g) R.p[g] = bl4x<AUX_SC1>(pp, g * GS < H ? co : OOB, g * GS < H ? g * GS * gstride : 0u);
+  }
+}
+// PRE: the first attempt's loads were issued by the caller (bwd_poll_issue) AHEAD of the visit's other requests -- vector memory
+// returns in order, and behind a dozen loads that come from HBM the first look at the rows was 2 us late even when they were there
+template <bool X0, int GS, bool PRE = false>
 __device__ __forceinline__ bool bwd_poll_rows(Red4Regs &R, const float *res_base, const float *part_base, int d, int H, unsigned tag,
-                                              const PipeSync &ps, int phase, int cluster) {
+                                              const PipeSync &ps, int phase, int cluster, int visit = 0) {
+  (void)visit;
   const int row = wave_id(), q = lane_id();
   const bool live = q < (d >> 2);
-  const unsigned co = live ? (unsigned)q * 16u : OOB, gstride = 16u * d * 4u;
   const unsigned probe = q < 4 ? (unsigned)q * 16u : OOB;
   const rsrc_t res = mk_rsrc(res_base + (size_t)row * d);
-  const rsrc_t pp = mk_rsrc(part_base + (size_t)row * d);
+  const rsrc_t pp = mk_rsrc(part_base + (size_t)row * H * d);
   unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
     asm volatile("" ::: "memory");
-    R.res = bl4x<AUX_SC1>(res, co);
+#ifdef BW_NO_PRE
+    bwd_poll_issue<X0, GS>(R, res_base, part_base, d, H);
+#else
+    if (!(PRE && tries == 0)) bwd_poll_issue<X0, GS>(R, res_base, part_base, d, H);
+#endif
     bool ok = !live || tag_ok(R.res, tag);
     if constexpr (!X0) {
 #pragma unroll
-      for (int g = 0; g < 8 / GS; ++g) {
-        R.p[g] = bl4x<AUX_SC1>(pp, g * GS < H ? co : OOB, g * GS < H ? g * GS * gstride : 0u);
-        ok = ok && (g * GS >= H || !live || tag_ok(R.p[g], tag));
-      }
+      for (int g = 0; g < 8 / GS; ++g) ok = ok && (g * GS >= H || !live || tag_ok(R.p[g], tag));
 #pragma unroll
       for (int g = 8 / GS; g < 8; ++g) R.p[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
       for (int g = 0; g < 8; ++g) R.p[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#ifdef MMT_PROFILE
+    if (tries == 0) PSTAMP(visit, 9);
+    if (__all(ok)) {
+      const int v_ = (visit >> 12) * 16 + (visit & 4095);
+      if (thread_idx() == 0 && blockIdx.x < PPR_WGS && (visit & 4095) < 16 && v_ < PPR_VISITS) g_pprof[blockIdx.x][v_][10] = (unsigned long long)tries;
+    }
+#endif
     if (__all(ok)) return true;
     if (!t0) t0 = wall_clock64();
     if (tries > 0) {
@@ -99,10 +130,14 @@ __device__ __forceinline__ bool bwd_poll_rows(Red4Regs &R, const float *res_base
       }
       continue;
     }
-    for (unsigned n = 0;; ++n) {         // thin polling: 64 bytes of the last row that arrives
+    // thin polling: 64 bytes of the part that arrives last -- slice 0's: that workgroup also writes the residual row and the two
+    // stash rows of the stage (measured with the last slice's part as the probe: the full fetch behind a matching probe usually met
+    // a missing part 0 and was repeated two or three times, 0.85 us each)
+#ifdef BW_OLD_PROBE
+    for (unsigned n = 0;; ++n) {
       __builtin_amdgcn_s_sleep(2);
       asm volatile("" ::: "memory");
-      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, (unsigned)(H - GS) * gstride);
+      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, 0u);
       if (__all(q >= 4 || tag_ok(v, tag))) break;
       if ((n & 15u) == 15u) {
         const bool late = wall_clock64() - t0 > PIPE_WAIT_TICKS;
@@ -115,6 +150,42 @@ __device__ __forceinline__ bool bwd_poll_rows(Red4Regs &R, const float *res_base
         }
       }
     }
+#else
+    // BW_PROBES probes are kept in flight: a probe takes a memory round trip (past the L2: ~0.7 us), and every workgroup of a stage
+    // notices its input at a random phase of its probe period -- the consumer of 8 parts waits for the last of 8 such phases
+    {
+      auto probe_load = [&]() -> f32x4 { return X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, 0u); };
+      f32x4 pv[BW_PROBES];
+#pragma unroll
+      for (int i = 0; i < BW_PROBES; ++i) {
+        asm volatile("" ::: "memory");
+        pv[i] = probe_load();
+      }
+      bool out = false;
+      for (unsigned n = 0; !out; ++n) {
+#pragma unroll
+        for (int i = 0; i < BW_PROBES; ++i) {
+          if (out) break;
+          const f32x4 v = pv[i];
+          asm volatile("" ::: "memory");
+          pv[i] = probe_load();              // (issued before v is looked at: the others stay in flight)
+          asm volatile("" ::: "memory");
+          if (__all(q >= 4 || tag_ok(v, tag))) out = true;
+          else __builtin_amdgcn_s_sleep(BW_PROBE_SLEEP);
+        }
+        if (!out && (n & 7u) == 7u) {
+          const bool late = wall_clock64() - t0 > PIPE_WAIT_TICKS;
+          if (late || __hip_atomic_load(ps.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (q == 0) {
+              if (late) pipe_give_up(ps, phase + 1000 * row + 500000 + (X0 ? 100000 : 0), cluster);
+              else *ps.abort = 1;
+            }
+            return false;
+          }
+        }
+      }
+    }
+#endif
   }
 }
 
@@ -303,15 +374,25 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
     const int s = ph - 1 - sp;
     const unsigned p = (unsigned)(sp * NP + kst);
     const unsigned tag_out = tag_of_phase(p), tag_in = tag_of_phase(p - 1u);
-    float *part_out = f.part[p & 1] + bwd_rowblock(p, d), *xres_out = f.xres[p & 1] + bwd_rowblock(p, d);
-    const float *part_in = f.part[(p + 1) & 1] + bwd_rowblock(p - 1u, d), *xres_in = f.xres[(p + 1) & 1] + bwd_rowblock(p - 1u, d);
+    float *part_out = f.part[p & 1] + bwd_rowblock(p, d) * H, *xres_out = f.xres[p & 1] + bwd_rowblock(p, d);
+    const float *part_in = f.part[(p + 1) & 1] + bwd_rowblock(p - 1u, d) * H, *xres_in = f.xres[(p + 1) & 1] + bwd_rowblock(p - 1u, d);
     const size_t srow = (size_t)s * B;             // first row of step s in a step-major (ph, B, .) stash
     int li = 0;
 #pragma clang loop unroll(disable)
     for (int m = replica; m < f.NC; m += f.R, ++li) {
       if (f.test_stall && sp == 1 && layer == 1 && KIND == BK_B && g0 == 0 && m == replica) return;   // its successors must time out
       const int a0 = m * 4, na = min(4, B - a0);
-      // ---- 0. everything that does not depend on the previous phase: requested before the poll
+      const int visit = sp * 4096 + li;
+      (void)visit;
+      PSTAMP(visit, 0);
+      // ---- 0. the first look at the previous phase's rows goes out first, then everything that does not depend on them
+      Red4Regs R;
+      if (red_wave) {
+        if (loadx) bwd_poll_issue<true, 1>(R, f.x0buf + (size_t)m * 4 * d, nullptr, d, H);
+        else if constexpr (KIND == BK_B) bwd_poll_issue<false, 2>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H);
+        else bwd_poll_issue<false, 1>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H);
+      }
+      __builtin_amdgcn_sched_barrier(0);           // (the compiler must not move the requests below ahead of these)
       BwdRow X;
       if (red_wave) bwd_row_issue(X, W.xhat[KIND] + srow * d, W.rstd[KIND] + srow, a0 + wv, B, d);
       unsigned k_ln = 0u, k_att = 1u;
@@ -333,16 +414,22 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
           }
         }
       }
-      float f1v = 0.f;
+      float f1v[NH];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) f1v[h] = 0.f;
       f32x4 kvr[NH][DH / 16], oldr[NH][DH / 16], qr = (f32x4){0.f, 0.f, 0.f, 0.f};
       float Pl = 0.f;
       const int nkeys = KIND == BK_B ? T : s + 1;
       if constexpr (KIND == BK_C) {
         constexpr int cgw = (FS / 4) >> 3;
         const int b = lane >> 2, j = lane & 3, r = b >> 2, bb = b & 3;
-        f1v = bl1(mk_rsrc(W.f1 + srow * (size_t)(FS * H)), (bb < cgw && r < na) ? (unsigned)((a0 + r) * (FS * H) + g0 * FS + (wv * cgw + bb) * 4 + j) * 4u : OOB);
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          f1v[h] = bl1(mk_rsrc(W.f1 + srow * (size_t)(FS * H)), (bb < cgw && r < na) ? (unsigned)((a0 + r) * (FS * H) + (g0 + h) * FS + (wv * cgw + bb) * 4 + j) * 4u : OOB);
       } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's accumulator stores of the previous visit have left
+        // the accumulator rows are read back by the thread that stored them; with one cluster per replica the previous visit's stores
+        // go to the very same addresses: let them leave first (otherwise the next visit is to another cluster)
+        if (f.NC <= f.R) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
           const int g = g0 + h;
@@ -354,7 +441,7 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
             if constexpr (KIND == BK_B) {
               const unsigned off = (unsigned)(((a0 + ag) * T + j) * 2 * d + kv * d + g * DH + 4 * c4) * 4u;
               kvr[h][it] = bl4(mk_rsrc(W.mkv), ok ? off : OOB);
-              oldr[h][it] = bl4(mk_rsrc(W.gmkv), ok ? off : OOB);
+              oldr[h][it] = (f32x4){0.f, 0.f, 0.f, 0.f};      // (the accumulator rows are read behind the attention: below)
             } else {
               const unsigned off = (unsigned)((j * B + a0 + ag) * 3 * d + (1 + kv) * d + g * DH + 4 * c4) * 4u;
               kvr[h][it] = bl4(mk_rsrc(W.qkv), ok ? off : OOB);
@@ -377,12 +464,12 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
         }
       }
       // ---- 1. the previous phase's rows
-      Red4Regs R;
       if (red_wave) {
-        if (loadx) (void)bwd_poll_rows<true, 1>(R, f.x0buf + (size_t)m * 4 * d, nullptr, d, H, (unsigned)sp & TAG_MASK, ps, (int)p, m);
-        else if constexpr (KIND == BK_A) (void)bwd_poll_rows<false, 2>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H, tag_in, ps, (int)p, m);
-        else (void)bwd_poll_rows<false, 1>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H, tag_in, ps, (int)p, m);
+        if (loadx) (void)bwd_poll_rows<true, 1, true>(R, f.x0buf + (size_t)m * 4 * d, nullptr, d, H, (unsigned)sp & TAG_MASK, ps, (int)p, m, visit);
+        else if constexpr (KIND == BK_B) (void)bwd_poll_rows<false, 2, true>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H, tag_in, ps, (int)p, m, visit);
+        else (void)bwd_poll_rows<false, 1, true>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H, tag_in, ps, (int)p, m, visit);
       }
+      PSTAMP(visit, 1);
       // ---- 2. LayerNorm backward -> xs; K / V rows and the queries -> staging tiles
       if (red_wave) {
         const size_t ro = (srow + a0 + wv) * d;
@@ -401,20 +488,25 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
           }
         if (wv < NH && lane < 32) *reinterpret_cast<f32x4 *>(S.qs + (wv * 4 + (lane >> 3)) * LDQ + 4 * (lane & 7)) = qr;
       }
+      PSTAMP(visit, 7);
       __syncthreads();
       if (*ps.abort) return;
+      PSTAMP(visit, 2);
       // ---- 3. first linear
       if constexpr (KIND == BK_C) {
         constexpr int cgw = (FS / 4) >> 3;
-        const float tot = bwd_gemm1_tot<DH, PHASE, D, FS>(M[0], S.xs, ldx);
-        const int b = lane >> 2, j = lane & 3, r = b >> 2, bb = b & 3;
-        if (bb < cgw) {
-          const int col = (wv * cgw + bb) * 4 + j;
-          // relu'(hidden) (rows beyond the batch: f1v = 0); with dropout on the hidden units the stash holds keep * scale * relu(.),
-          // whose derivative is scale where it is positive
-          const float v = f1v > 0.f ? (DROP ? tot * s_ff : tot) : 0.f;
-          S.t1[r * LD1 + col] = v;
-          if (r < na) W.gf1[(srow + a0 + r) * (size_t)(FS * H) + g0 * FS + col] = v;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const float tot = bwd_gemm1_tot<DH, PHASE, D, FS>(M[h], S.xs, ldx);
+          const int b = lane >> 2, j = lane & 3, r = b >> 2, bb = b & 3;
+          if (bb < cgw) {
+            const int col = (wv * cgw + bb) * 4 + j;
+            // relu'(hidden) (rows beyond the batch: f1v = 0); with dropout on the hidden units the stash holds keep * scale * relu(.),
+            // whose derivative is scale where it is positive
+            const float v = f1v[h] > 0.f ? (DROP ? tot * s_ff : tot) : 0.f;
+            S.t1[(h * 4 + r) * LD1 + col] = v;
+            if (r < na) W.gf1[(srow + a0 + r) * (size_t)(FS * H) + (g0 + h) * FS + col] = v;
+          }
         }
       } else {
 #pragma unroll
@@ -425,22 +517,8 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
         }
       }
       __syncthreads();
-      // ---- 4. attention backward (wave h: head g0 + h), then the K / V gradient units on every thread
-      if constexpr (KIND != BK_C) {
-        if (wv < NH) {
-          const int h = wv;
-          attend4_bwd<DH>(na, nkeys, Pl, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
-                          S.pp + h * 64, S.t2 + h * 4 * LD1, LD1, k_att, s_att);
-          // dq -> stash (gcq / the q columns of gqkv): lane (ar, l16) holds DH/16 = 2 consecutive columns
-          const int ar = lane >> 4, l16 = lane & 15, g = g0 + h;
-          if (ar < na) {
-            const float2 v2 = *reinterpret_cast<const float2 *>(S.t2 + (h * 4 + ar) * LD1 + l16 * 2);
-            if constexpr (KIND == BK_B) *reinterpret_cast<float2 *>(W.gcq + (srow + a0 + ar) * d + g * DH + l16 * 2) = v2;
-            else *reinterpret_cast<float2 *>(W.gqkv + (srow + a0 + ar) * 3 * d + g * DH + l16 * 2) = v2;
-          }
-        }
-        __syncthreads();
-        // dK_j += scale dS_j q, dV_j += P_j dO: the workgroup owns its heads' rows (read-modify-write, no atomics)
+      PSTAMP(visit, 3);
+      auto kv_grad_units = [&]() {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
           const int g = g0 + h;
@@ -457,34 +535,75 @@ __device__ __forceinline__ void bwd_stage(const BwdPipeArgs &f, int layer, int g
               for (int e = 0; e < 4; ++e) nv[e] = fmaf(wgt, src[e], nv[e]);
               if constexpr (KIND == BK_B) {
                 *reinterpret_cast<f32x4 *>(W.gmkv + (size_t)((a0 + ag) * T + j) * 2 * d + kv * d + g * DH + 4 * c4) = nv;
-              } else {
+              } else if constexpr (KIND == BK_A) {
                 *reinterpret_cast<f32x4 *>(W.gqkv + (size_t)(j * B + a0 + ag) * 3 * d + (1 + kv) * d + g * DH + 4 * c4) = nv;
                 if (j == s) *reinterpret_cast<f32x4 *>(S.t2 + ag * LD1 + (1 + kv) * DH + 4 * c4) = nv;     // row s is complete now
               }
             }
           }
         }
+      };
+      // ---- 4. attention backward (wave h: head g0 + h), then the K / V gradient units on every thread
+      if constexpr (KIND != BK_C) {
+        if (wv < NH) {
+          const int h = wv;
+          attend4_bwd<DH>(na, nkeys, Pl, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
+                          S.pp + h * 64, S.t2 + h * 4 * LD1, LD1, k_att, s_att);
+          // dq -> stash (gcq / the q columns of gqkv): lane (ar, l16) holds DH/16 = 2 consecutive columns
+          const int ar = lane >> 4, l16 = lane & 15, g = g0 + h;
+          if (ar < na) {
+            const float2 v2 = *reinterpret_cast<const float2 *>(S.t2 + (h * 4 + ar) * LD1 + l16 * 2);
+            if constexpr (KIND == BK_B) *reinterpret_cast<float2 *>(W.gcq + (srow + a0 + ar) * d + g * DH + l16 * 2) = v2;
+            else *reinterpret_cast<float2 *>(W.gqkv + (srow + a0 + ar) * 3 * d + g * DH + l16 * 2) = v2;
+          }
+        }
+        __syncthreads();
+        // dK_j += scale dS_j q, dV_j += P_j dO: the workgroup owns its heads' rows (read-modify-write, no atomics).  The self-attention
+        // stage needs row s before its second linear; the cross-attention stage does this behind the hand-off (below)
+        PSTAMP(visit, 8);
+        if constexpr (KIND == BK_B) {      // the memory K / V gradient rows this visit adds to: needed behind the hand-off only
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int it = 0; it < DH / 16; ++it) {
+              int ag, j, kv, c4;
+              kv_unit<DH>(tid + CNT * it, ag, j, kv, c4);
+              oldr[h][it] = bl4(mk_rsrc(W.gmkv), (ag < na && j < nkeys) ? (unsigned)(((a0 + ag) * T + j) * 2 * d + kv * d + (g0 + h) * DH + 4 * c4) * 4u : OOB);
+            }
+        }
+        if constexpr (KIND == BK_A) kv_grad_units();
         if constexpr (KIND == BK_A) __syncthreads();
       }
+      PSTAMP(visit, 4);
       // ---- 5. second linear: one tagged part per head / slice, write-through
-      if constexpr (KIND == BK_C) {
-        gemm2_4s<DH, PHASE, D, FS, AUX_SC1>(M[0], S.t1, LD1, part_out + ((size_t)m * H + g0) * 16 * d, tag_out);
-      } else if constexpr (KIND == BK_B) {
-        static_assert(NH == 2, "cross-attention stage: two heads, one pre-summed part");
-        gemm2_4s_pair<DH, PHASE, D, FS, AUX_SC1>(M, S.t2, LD1, 4 * LD1, part_out + ((size_t)m * H + g0) * 16 * d, tag_out);
-      } else {
-        typedef Lin4S<D / 4, DH / 4> L2;
+      {
+        typedef Lin4S<D / 4, (PHASE == PH_C ? FS : DH) / 4> L2;
         const int b = lane >> 2, j = lane & 3;
-        f32x4 acc = gemm2_4s_acc<DH, PHASE, D, FS>(M[0], S.t2, LD1);
-        acc += gemm2_4s_acc<DH, PHASE, D, FS>(M[1], S.t2 + DH, LD1);
-        acc += gemm2_4s_acc<DH, PHASE, D, FS>(M[2], S.t2 + 2 * DH, LD1);
-        quad_transpose(acc, j);
+        f32x4 acc;
+        if constexpr (KIND == BK_C) {
+          // two feed-forward slices per workgroup: ONE pre-summed part (in the slot of the even slice) - half the rows for the
+          // cross-attention stage to fetch; that stage is the sweep's busiest, so it has one head per workgroup and this one two slices
+          static_assert(NH == 2, "feed-forward stage: two slices, one pre-summed part");
+          acc = tag4(gemm2_4s_acc<DH, PHASE, D, FS>(M[0], S.t1, LD1), tag_out) + tag4(gemm2_4s_acc<DH, PHASE, D, FS>(M[1], S.t1 + 4 * LD1, LD1), tag_out);
+        } else if constexpr (KIND == BK_B) {
+          static_assert(NH == 1, "cross-attention stage: one head per workgroup");
+          acc = gemm2_4s_acc<DH, PHASE, D, FS>(M[0], S.t2, LD1);
+        } else {
+          acc = gemm2_4s_acc<DH, PHASE, D, FS>(M[0], S.t2, LD1);
+          acc += gemm2_4s_acc<DH, PHASE, D, FS>(M[1], S.t2 + DH, LD1);
+          acc += gemm2_4s_acc<DH, PHASE, D, FS>(M[2], S.t2 + 2 * DH, LD1);
+        }
+        quad_transpose(acc, j);                      // lane j of a quad: row j, the quad's 4 columns -> one 16-byte store
         acc = tag4(acc, tag_out);
-        bs4x<AUX_SC1>(mk_rsrc(part_out + ((size_t)m * H + g0) * 16 * d), b < L2::cgw ? (unsigned)(j * D + (wv * L2::cgw + b) * 4) * 4u : OOB, acc);
+        // part g0 of row j of the cluster: [16 rows][H][d]
+        bs4x<AUX_SC1>(mk_rsrc(part_out + (size_t)m * 16 * H * d + (size_t)g0 * d), b < L2::cgw ? (unsigned)(j * H * D + (wv * L2::cgw + b) * 4) * 4u : OOB, acc);
+        if constexpr (KIND == BK_B) kv_grad_units();      // off the hop: the part is on its way
       }
+      PSTAMP(visit, 5);
       // (the next visit's barrier behind its poll orders this visit's LDS reads before the next writes of xs / t1 / tiles ... except
       // the staging tiles, which are written before that barrier: one more barrier here)
       __syncthreads();
+      PSTAMP(visit, 6);
     }
   }
 }
@@ -517,11 +636,15 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
   for (int sp = 0; sp <= ph; ++sp) {
     const int s = ph - 1 - sp;                       // -1 on the last visit: only gx[0][0] is reduced
     const unsigned p = (unsigned)(sp * NP);          // the phase the step's first stage runs as; this visit consumes phase p - 1
-    const float *part_in = f.part[(p + 1) & 1] + bwd_rowblock(p - 1u, d), *xres_in = f.xres[(p + 1) & 1] + bwd_rowblock(p - 1u, d);
+    const float *part_in = f.part[(p + 1) & 1] + bwd_rowblock(p - 1u, d) * H, *xres_in = f.xres[(p + 1) & 1] + bwd_rowblock(p - 1u, d);
+    int li = 0;
 #pragma clang loop unroll(disable)
-    for (int m = replica + jh * f.R; m < f.NC; m += f.R * f.NHW) {
+    for (int m = replica + jh * f.R; m < f.NC; m += f.R * f.NHW, ++li) {
       const int a0 = m * 4, na = min(4, B - a0), ag = a0 + wv;
       const bool mine = red_wave && ag < B;
+      const int visit = sp * 4096 + li;
+      (void)visit;
+      PSTAMP(visit, 0);
       // ---- 0. prefetch: the head tape of step s (independent of the previous phase)
       unsigned k_pe = 0u;
       if constexpr (DROP) {      // PositionalEncoding's dropout: the gradient at the embedding of step s + 1
@@ -529,8 +652,10 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
           k_pe = __builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(A.k_pe), (A.k_pe && mine && lane < (d >> 2))
                                                           ? (unsigned)(((s + 1) * B + ag) * d + 4 * lane) : OOB, 0, 0);
       }
-      float huv = 0.f, hxh = 0.f, hrs = 0.f;
+      float huv = 0.f, hxh = 0.f, hrs = 0.f, dl0 = 0.f, dl1 = 0.f;
       if (red_wave && s >= 0) {
+        dl0 = bl1(mk_rsrc(A.G), mine ? (unsigned)(((s + 1) * B + ag) * 2 + 0) * 4u : OOB);
+        dl1 = bl1(mk_rsrc(A.G), mine ? (unsigned)(((s + 1) * B + ag) * 2 + 1) * 4u : OOB);
         huv = bl1(mk_rsrc(A.h_hu), (mine && c < NO && lane < 32) ? (unsigned)((s * B + ag) * NO + c) * 4u : OOB);
         hxh = bl1(mk_rsrc(A.h_xhat), (mine && c < NO && lane < 32) ? (unsigned)((s * B + ag) * NO + c) * 4u : OOB);
         hrs = bl1(mk_rsrc(A.h_rstd), mine ? (unsigned)(s * B + ag) * 4u : OOB);
@@ -542,8 +667,10 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
       if (sp > 0) {
         if (red_wave) (void)bwd_poll_rows<false, 1>(R, xres_in + (size_t)m * 16 * d, part_in + (size_t)m * H * 16 * d, d, H, tag_of_phase(p - 1u), ps, (int)p, m);
       }
+      PSTAMP(visit, 1);
       __syncthreads();
       if (*ps.abort) return;
+      PSTAMP(visit, 2);
       if (red_wave) {
         float d0 = 0.f, d1 = 0.f;
         if (sp > 0) {        // gx[0][s + 1] = residual + parts; its product with W_in
@@ -563,21 +690,27 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
           d1 = wave64_total(t1);
         }
         if (s >= 0) {
-          // rows of A.G: [t] for t = 0..ph; dL/dpos[s + 1] sits in row s + 1; the total of step s + 2 was left in row s + 2 by
-          // this very wave one visit of this cluster earlier (sc1: past this CU's L1)
-          const rsrc_t rG = mk_rsrc(A.G);
-          const float dl0 = bl1(rG, mine ? (unsigned)(((s + 1) * B + ag) * 2 + 0) * 4u : OOB);
-          const float dl1 = bl1(rG, mine ? (unsigned)(((s + 1) * B + ag) * 2 + 1) * 4u : OOB);
+          // rows of A.G: [t] for t = 0..ph; dL/dpos[s + 1] sits in row s + 1 (requested before the poll); the total of step s + 2
+          // was left in LDS by this very wave at its previous visit of this cluster
           float n0 = 0.f, n1 = 0.f;
           if (sp > 0) {
-            n0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rG, mine ? (unsigned)(((s + 2) * B + ag) * 2 + 0) * 4u : OOB, 0, AUX_SC1));
-            n1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rG, mine ? (unsigned)(((s + 2) * B + ag) * 2 + 1) * 4u : OOB, 0, AUX_SC1));
+            if (li < BW_MAXPOS) {
+              n0 = S.qs[(li * 4 + wv) * 2 + 0];
+              n1 = S.qs[(li * 4 + wv) * 2 + 1];
+            } else {       // (more clusters per head workgroup than the LDS table holds: from memory, past this CU's L1)
+              const rsrc_t rG = mk_rsrc(A.G);
+              n0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rG, mine ? (unsigned)(((s + 2) * B + ag) * 2 + 0) * 4u : OOB, 0, AUX_SC1));
+              n1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rG, mine ? (unsigned)(((s + 2) * B + ag) * 2 + 1) * 4u : OOB, 0, AUX_SC1));
+            }
           }
           gt0 = dl0 + (n0 + d0);
           gt1 = dl1 + (n1 + d1);
-          if (mine && sp > 0 && lane == 0) {
-            A.G[((size_t)(s + 1) * B + ag) * 2 + 0] = gt0;
-            A.G[((size_t)(s + 1) * B + ag) * 2 + 1] = gt1;
+          if (lane == 0) {
+            if (li < BW_MAXPOS) S.qs[(li * 4 + wv) * 2 + 0] = gt0, S.qs[(li * 4 + wv) * 2 + 1] = gt1;
+            if (mine && sp > 0) {
+              A.G[((size_t)(s + 1) * B + ag) * 2 + 0] = gt0;
+              A.G[((size_t)(s + 1) * B + ag) * 2 + 1] = gt1;
+            }
           }
           // ---- decoder/MLP backward of step s for this row (MLP.py:12-24): lanes 0..31 = columns
           const float ghu = gt0 * wo0 + gt1 * wo1;
@@ -601,12 +734,16 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
           }
         }
       }
+      PSTAMP(visit, 3);
       __syncthreads();
+      PSTAMP(visit, 4);
       if (s >= 0) {
         // ---- gx[L][s] = gho W_out: the 4 rows go to x0buf, tagged with the step, for the last layer's feed-forward stage
         gemm2_4s<DH, PH_B, D, FS, AUX_SC1>(Mo, S.t1, LD1, f.x0buf + (size_t)m * 4 * d, (unsigned)sp & TAG_MASK);
       }
+      PSTAMP(visit, 5);
       __syncthreads();
+      PSTAMP(visit, 6);
       (void)na;
     }
   }
@@ -626,8 +763,8 @@ __global__ __launch_bounds__(CNT) void mmt_bwd_pipe4_kernel(BwdPipeArgs f) {
   if (rb < L * per_layer) {
     const int layer = rb / per_layer, q = rb - layer * per_layer;
     if (q < H) bwd_stage<DH, BK_A, 1, D, FS, DROP>(f, layer, q, replica, S, ps);
-    else if (q < H + H / 2) bwd_stage<DH, BK_B, 2, D, FS, DROP>(f, layer, 2 * (q - H), replica, S, ps);
-    else bwd_stage<DH, BK_C, 1, D, FS, DROP>(f, layer, q - H - H / 2, replica, S, ps);
+    else if (q < 2 * H) bwd_stage<DH, BK_B, 1, D, FS, DROP>(f, layer, q - H, replica, S, ps);
+    else bwd_stage<DH, BK_C, 2, D, FS, DROP>(f, layer, 2 * (q - 2 * H), replica, S, ps);
   } else {
     bwd_head<DH, D, FS, DROP>(f, replica, rb - L * per_layer, S, ps);
   }
