@@ -1742,6 +1742,15 @@ __device__ __forceinline__ PipeLds pipe_lds(float *smem, int d) {
   return L;
 }
 
+#ifndef FW_PROBES
+#define FW_PROBES 1
+#endif
+#ifndef FW_PROBE_SLOT0
+#define FW_PROBE_SLOT0 0
+#endif
+#ifndef FW_POLL_FIRST
+#define FW_POLL_FIRST 0
+#endif
 // ---- data-tagged hand-off (see "tag bits" above): the consumer's red waves poll the rows themselves --------------------------
 constexpr unsigned long long PIPE_WAIT_TICKS = 20000000ull;     // 0.2 s of the 100 MHz wall clock: a wait this long = give up
 struct PipeSync {
@@ -1765,7 +1774,20 @@ __device__ __forceinline__ void pipe_give_up(const PipeSync &ps, int phase, int 
 // everything again.  Returns false when it gave up (wave-uniform).
 // GS: stride of the part slots that exist (2 behind the cross-attention stage, whose workgroups hand over one pre-summed part
 // for their two heads, in the slot of the even head)
+// the loads of one full attempt (poll_rows<.., PRE = true>: the caller issues the first attempt AHEAD of the visit's other requests -
+// vector memory returns in order)
 template <bool X0, int GS = 1>
+__device__ __forceinline__ void poll_issue(Red4Regs &R, const ClArgs &a, const float *x0buf, int cluster) {
+  const int row = wave_id(), q = lane_id();
+  const unsigned co = q < (a.d >> 2) ? (unsigned)q * 16u : OOB, gstride = 16u * a.d * 4u;
+  R.res = bl4x<AUX_SC1>(mk_rsrc(X0 ? x0buf + ((size_t)cluster * 4 + row) * a.d : a.xres_in + ((size_t)cluster * 16 + row) * a.d), co);
+  if constexpr (!X0) {
+    const rsrc_t pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
+#pragma unroll
+    for (int g = 0; g < 8 / GS; ++g) R.p[g] = bl4x<AUX_SC1>(pp, g * GS < a.H ? co : OOB, g * GS < a.H ? g * GS * gstride : 0u);
+  }
+}
+template <bool X0, int GS = 1, bool PRE = false>
 __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const float *x0buf, int cluster, unsigned tag, const PipeSync &ps) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
@@ -1776,12 +1798,12 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
   unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
     asm volatile("" ::: "memory");       // the loads below are re-issued every pass (buffer loads are not volatile to the compiler)
-    R.res = bl4x<AUX_SC1>(res, co);
+    if (!(PRE && tries == 0)) R.res = bl4x<AUX_SC1>(res, co);
     bool ok = !live || tag_ok(R.res, tag);
     if constexpr (!X0) {
 #pragma unroll
       for (int g = 0; g < 8 / GS; ++g) {
-        R.p[g] = bl4x<AUX_SC1>(pp, g * GS < a.H ? co : OOB, g * GS < a.H ? g * GS * gstride : 0u);
+        if (!(PRE && tries == 0)) R.p[g] = bl4x<AUX_SC1>(pp, g * GS < a.H ? co : OOB, g * GS < a.H ? g * GS * gstride : 0u);
         ok = ok && (g * GS >= a.H || !live || tag_ok(R.p[g], tag));
       }
       if constexpr (GS > 1) {
@@ -1799,10 +1821,11 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
       }
       continue;
     }
+#if FW_PROBES <= 1
     for (unsigned n = 0;; ++n) {         // thin polling
       __builtin_amdgcn_s_sleep(2);
       asm volatile("" ::: "memory");
-      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, (unsigned)(a.H - GS) * gstride);
+      const f32x4 v = X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, FW_PROBE_SLOT0 ? 0u : (unsigned)(a.H - GS) * gstride);
       if (__all(q >= 4 || tag_ok(v, tag))) break;
       if ((n & 15u) == 15u) {
         const bool late = wall_clock64() - t0 > PIPE_WAIT_TICKS;
@@ -1815,6 +1838,43 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
         }
       }
     }
+#else
+    {   // FW_PROBES thin probes in flight (round 3, as the backward sweep's bwd_poll_rows): a probe takes a memory round trip, and
+        // every workgroup of a stage notices its input at a random phase of its probe period
+      auto probe_load = [&]() -> f32x4 {
+        return X0 ? bl4x<AUX_SC1>(res, probe) : bl4x<AUX_SC1>(pp, probe, FW_PROBE_SLOT0 ? 0u : (unsigned)(a.H - GS) * gstride);
+      };
+      f32x4 pv[FW_PROBES];
+#pragma unroll
+      for (int i = 0; i < FW_PROBES; ++i) {
+        asm volatile("" ::: "memory");
+        pv[i] = probe_load();
+      }
+      bool out = false;
+      for (unsigned n = 0; !out; ++n) {
+#pragma unroll
+        for (int i = 0; i < FW_PROBES; ++i) {
+          if (out) break;
+          const f32x4 v = pv[i];
+          asm volatile("" ::: "memory");
+          pv[i] = probe_load();
+          asm volatile("" ::: "memory");
+          if (__all(q >= 4 || tag_ok(v, tag))) out = true;
+          else __builtin_amdgcn_s_sleep(3);
+        }
+        if (!out && (n & 7u) == 7u) {
+          const bool late = wall_clock64() - t0 > PIPE_WAIT_TICKS;
+          if (late || __hip_atomic_load(ps.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (q == 0) {
+              if (late) pipe_give_up(ps, a.prof_idx + 1000 * row + (X0 ? 100000 : 0), cluster);
+              else *ps.abort = 1;
+            }
+            return false;
+          }
+        }
+      }
+    }
+#endif
   }
 }
 
@@ -1896,7 +1956,7 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
 template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false>
 __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, int cluster, int g0, bool loadx, const PipeLds &S,
                                            const PipeSync &ps, MainRegs4<DH, PHASE> (&M)[NH], int &pad, bool kv_ready, int nx_step,
-                                           int nx_cluster, int visit) {
+                                           int nx_cluster, int visit, bool wait_appends = true) {
   constexpr int AUX = AUX_SC1;
   constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
   const int d = a.d, ldx = d + MMT_PAD, tid = thread_idx();
@@ -1914,14 +1974,27 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
                                                     ? (unsigned)((b0 + ar) * a.T + l16) : OOB, 0, 0);
     }
   };
+  Red4Regs R;
+  const bool red_wave = wave_id() < 4;
+#if FW_POLL_FIRST
+  // ---- 0a. the first look at the previous phase's rows goes out AHEAD of everything else the visit requests
+  if (red_wave) {
+    if (loadx) poll_issue<true>(R, a, x0buf, cluster);
+    else poll_issue<false, PHASE == PH_C ? 2 : 1>(R, a, x0buf, cluster);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // ---- 0. this cluster's K/V cache rows do not depend on the previous phase: requested first, staged once the poll is through
   if (!kv_ready) {
+#if FW_POLL_FIRST
+    // (the cache rows of this cluster were appended a whole step ago unless the replica has a single cluster)
+    if constexpr (PHASE == PH_A) { if (wait_appends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
     if constexpr (PHASE == PH_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's earlier cache appends have left
+#endif
     kv_request(cluster, a.s);
   }
   // ---- 1. the previous phase's rows, polled until they carry its tag
-  Red4Regs R;
-  const bool red_wave = wave_id() < 4;
   bool got = true;
   // training-mode dropout: this visit's keep bytes do not depend on the previous phase either -- requested before the poll
   // (branch-free: a load under a branch makes the compiler wait for everything in flight where the branch rejoins)
@@ -1951,8 +2024,8 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
       R.gam = bl4(mk_rsrc(a.red_ln.g), co);
       R.bet = bl4(mk_rsrc(a.red_ln.b), co);
     }
-    got = loadx ? poll_rows<true>(R, a, x0buf, cluster, (unsigned)a.s & TAG_MASK, ps)
-                : poll_rows<false, PHASE == PH_C ? 2 : 1>(R, a, x0buf, cluster, tag_in, ps);
+    got = loadx ? poll_rows<true, 1, FW_POLL_FIRST != 0>(R, a, x0buf, cluster, (unsigned)a.s & TAG_MASK, ps)
+                : poll_rows<false, PHASE == PH_C ? 2 : 1, FW_POLL_FIRST != 0>(R, a, x0buf, cluster, tag_in, ps);
   }
   (void)got;                                           // a wave that gave up has raised the abort flag
   PSTAMP(visit, 1);
@@ -2096,7 +2169,8 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
         if (m + f.R < f.NC) nx_cluster = m + f.R;
         else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
       }
-      if (!pipe_phase<DH, PHASE, NH, D, FS, DROP>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li)) return;
+      if (!pipe_phase<DH, PHASE, NH, D, FS, DROP>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li,
+                                                  f.NC <= f.R)) return;
       kv_ready = nx_cluster >= 0;
     }
   }
