@@ -497,14 +497,18 @@ def main():
         kr, dec_flops, dec_bytes = kernel_rooflines(args.mode, B, args.history, ph, hp, reg, kt, n_dec)
         achieved = dec_flops / (kt["decoder_ms"] * n_dec * 1e-3) / 1e12
         # HBM-side bytes per decode: only from a PMC pass (tools/pmc_summary.py) over kernels built from THIS source tree
-        traffic, traffic_src = None, "no rocprofv3 --pmc summary for this source tree (profiles/r02/traffic_b128_basic.json absent or stale)"
-        tf = os.path.join(ROOT, "profiles", "r02", "traffic_b128_basic.json")
-        if args.mode == "basic" and B == 128 and ph == 12 and args.history == 8 and os.path.exists(tf):
-            tj = json.load(open(tf))
-            if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("decoder_form") in kt["decoder_path"]:
-                traffic = tj["decoder_bytes_per_predict"]
-                traffic_src = ("profiles/r02/traffic_b128_basic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes over "
-                               "tools/decode_only.py on this source tree; counted at the L2's fabric side, Infinity-Cache hits included")
+        traffic, traffic_src = None, "no rocprofv3 --pmc summary for this source tree (profiles/r*/traffic_b128_basic.json absent or stale)"
+        if args.mode == "basic" and B == 128 and ph == 12 and args.history == 8:
+            for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):   # newest round first
+                tf = os.path.join(ROOT, "profiles", rnd, "traffic_b128_basic.json")
+                if not os.path.exists(tf):
+                    continue
+                tj = json.load(open(tf))
+                if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("decoder_form") in kt["decoder_path"]:
+                    traffic = tj["decoder_bytes_per_predict"]
+                    traffic_src = (f"profiles/{rnd}/traffic_b128_basic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes "
+                                   "over tools/decode_only.py on this source tree; counted at the L2's fabric side, Infinity-Cache hits included")
+                    break
         line = {
             "metric": "predicted agents/sec (12-step, batch 128)",
             "value": weak["value"], "unit": "agents/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1651,16 +1651,16 @@ __device__ __forceinline__ f32x4 gemm2_4s_acc(const MainRegs4<DH, PHASE> &M, con
 // two heads of one workgroup (cross attention): ONE part = tag(tag(part of head g0) + tag(part of head g0 + 1)), in the slot of g0
 template <int DH, int PHASE, int D, int FS, int AUX>
 __device__ __forceinline__ void gemm2_4s_pair(const MainRegs4<DH, PHASE> (&M)[2], const float *x2, int ld2, int hstride, float *part,
-                                              unsigned tag) {
+                                              unsigned tag, int ldp = D) {
   typedef Lin4S<D / 4, (PHASE == PH_C ? FS : DH) / 4> L2;
   const int w = wave_id(), lane = lane_id(), b = lane >> 2, j = lane & 3;
   const f32x4 a0 = gemm2_4s_acc<DH, PHASE, D, FS>(M[0], x2, ld2), a1 = gemm2_4s_acc<DH, PHASE, D, FS>(M[1], x2 + hstride, ld2);
   f32x4 acc = tag4(tag4(a0, tag) + tag4(a1, tag), tag);
   quad_transpose(acc, j);
-  bs4x<AUX>(mk_rsrc(part), b < L2::cgw ? (unsigned)(j * D + (w * L2::cgw + b) * 4) * 4u : OOB, acc);
+  bs4x<AUX>(mk_rsrc(part), b < L2::cgw ? (unsigned)(j * ldp + (w * L2::cgw + b) * 4) * 4u : OOB, acc);
 }
 template <int DH, int PHASE, int D, int FS, int AUX>
-__device__ __forceinline__ void gemm2_4s(const MainRegs4<DH, PHASE> &M, const float *x2, int ld2, float *part, unsigned tag) {
+__device__ __forceinline__ void gemm2_4s(const MainRegs4<DH, PHASE> &M, const float *x2, int ld2, float *part, unsigned tag, int ldp = D) {
   typedef Geom4<PHASE> G4;
   constexpr int K2q = (PHASE == PH_C ? FS : DH) / 4;
   typedef Lin4S<D / 4, K2q> L2;
@@ -1680,7 +1680,7 @@ __device__ __forceinline__ void gemm2_4s(const MainRegs4<DH, PHASE> &M, const fl
   for (int r = 0; r < 4; ++r) acc[r] = kparts_sum_s<L2::cgw>(acc[r]);
   quad_transpose(acc, j);                            // lane j of a quad: row j, the quad's 4 columns -> one 16-byte store
   acc = tag4(acc, tag);
-  bs4x<AUX>(mk_rsrc(part), b < L2::cgw ? (unsigned)(j * D + (w * L2::cgw + b) * 4) * 4u : OOB, acc);
+  bs4x<AUX>(mk_rsrc(part), b < L2::cgw ? (unsigned)(j * ldp + (w * L2::cgw + b) * 4) * 4u : OOB, acc);
 }
 
 // ------------------------------------------------------------------------------- weight-stationary pipeline (one launch)
@@ -1746,10 +1746,16 @@ __device__ __forceinline__ PipeLds pipe_lds(float *smem, int d) {
 #define FW_PROBES 1
 #endif
 #ifndef FW_PROBE_SLOT0
-#define FW_PROBE_SLOT0 0
+#define FW_PROBE_SLOT0 1        // probe the part of slice 0 (that workgroup also writes the residual row): 1.049 -> 1.044 ms at B = 128
 #endif
 #ifndef FW_POLL_FIRST
 #define FW_POLL_FIRST 0
+#endif
+#ifndef FW_COND_WAIT
+#define FW_COND_WAIT 0
+#endif
+#ifndef FW_ROW_PARTS
+#define FW_ROW_PARTS 0
 #endif
 // ---- data-tagged hand-off (see "tag bits" above): the consumer's red waves poll the rows themselves --------------------------
 constexpr unsigned long long PIPE_WAIT_TICKS = 20000000ull;     // 0.2 s of the 100 MHz wall clock: a wait this long = give up
@@ -1791,10 +1797,16 @@ template <bool X0, int GS = 1, bool PRE = false>
 __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const float *x0buf, int cluster, unsigned tag, const PipeSync &ps) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
+#if FW_ROW_PARTS
+  // parts of a cluster as [16 rows][H][d]: the H parts of a row are contiguous (as in the backward sweep, decoder_bwd_pipe.cuh)
+  const unsigned co = live ? (unsigned)q * 16u : OOB, gstride = (unsigned)a.d * 4u;
+  const rsrc_t pp = mk_rsrc(a.part_in + ((size_t)cluster * 16 + row) * a.H * a.d);
+#else
   const unsigned co = live ? (unsigned)q * 16u : OOB, gstride = 16u * a.d * 4u;
+  const rsrc_t pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
+#endif
   const unsigned probe = q < 4 ? (unsigned)q * 16u : OOB;
   const rsrc_t res = mk_rsrc(X0 ? x0buf + ((size_t)cluster * 4 + row) * a.d : a.xres_in + ((size_t)cluster * 16 + row) * a.d);
-  const rsrc_t pp = mk_rsrc(a.part_in + ((size_t)cluster * a.H * 16 + row) * a.d);
   unsigned long long t0 = 0;
   for (int tries = 0;; ++tries) {
     asm volatile("" ::: "memory");       // the loads below are re-issued every pass (buffer loads are not volatile to the compiler)
@@ -1956,7 +1968,7 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
 template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false>
 __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, int cluster, int g0, bool loadx, const PipeLds &S,
                                            const PipeSync &ps, MainRegs4<DH, PHASE> (&M)[NH], int &pad, bool kv_ready, int nx_step,
-                                           int nx_cluster, int visit, bool wait_appends = true) {
+                                           int nx_cluster, int visit, bool wait_appends = true, bool last_phase = false) {
   constexpr int AUX = AUX_SC1;
   constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
   const int d = a.d, ldx = d + MMT_PAD, tid = thread_idx();
@@ -1986,7 +1998,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
 #endif
   // ---- 0. this cluster's K/V cache rows do not depend on the previous phase: requested first, staged once the poll is through
   if (!kv_ready) {
-#if FW_POLL_FIRST
+#if FW_POLL_FIRST || FW_COND_WAIT
     // (the cache rows of this cluster were appended a whole step ago unless the replica has a single cluster)
     if constexpr (PHASE == PH_A) { if (wait_appends) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #else
@@ -2087,13 +2099,22 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   }
   PSTAMP(visit, 4);
   // ---- 5. K-slices of the output projection: one tagged partial [4][d] per head / slice, write-through, nothing to wait for
+#if FW_ROW_PARTS
+  // row-major parts inside the pipeline; the decode's LAST phase keeps the [H][16][d] layout the final head launch reads
+  const int ldp = last_phase ? D : a.H * D;
+  auto part_of = [&](int g) -> float * {
+    return last_phase ? a.part_out + ((size_t)cluster * a.H + g) * 16 * d : a.part_out + (size_t)cluster * 16 * a.H * d + (size_t)g * d;
+  };
+#else
+  constexpr int ldp = D;
+  auto part_of = [&](int g) -> float * { return a.part_out + ((size_t)cluster * a.H + g) * 16 * d; };
+#endif
   if constexpr (NH == 2) {
-    gemm2_4s_pair<DH, PHASE, D, FS, AUX>(M, S.ob, LDO, 4 * LDO, a.part_out + ((size_t)cluster * a.H + g0) * 16 * d, tag_out);
+    gemm2_4s_pair<DH, PHASE, D, FS, AUX>(M, S.ob, LDO, 4 * LDO, part_of(g0), tag_out, ldp);
   } else {
 #pragma unroll
     for (int h = 0; h < NH; ++h)
-      gemm2_4s<DH, PHASE, D, FS, AUX>(M[h], PHASE == PH_C ? S.t1 : S.ob + h * 4 * LDO, PHASE == PH_C ? LD1 : LDO,
-                                      a.part_out + ((size_t)cluster * a.H + g0 + h) * 16 * d, tag_out);
+      gemm2_4s<DH, PHASE, D, FS, AUX>(M[h], PHASE == PH_C ? S.t1 : S.ob + h * 4 * LDO, PHASE == PH_C ? LD1 : LDO, part_of(g0 + h), tag_out, ldp);
   }
   PSTAMP(visit, 5);
   PSTAMP(visit, 6);
@@ -2140,9 +2161,16 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
     // decode lands in rows 0..3, where the final head launch looks for it)
     const unsigned p_last = (unsigned)(NP * f.a.ph - 1);
     const size_t rb_out = (size_t)4 * (((p_last - p) >> 1) & 3u) * f.a.d, rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
+#if FW_ROW_PARTS
+    const bool last_phase = p == p_last;
+    a.part_out = f.part[p & 1] + (last_phase ? rb_out : rb_out * f.a.H);
+    a.part_in = f.part[(p + 1) & 1] + rb_in * f.a.H;
+#else
+    const bool last_phase = false;
     a.part_out = f.part[p & 1] + rb_out;
-    a.xres_out = f.xres[p & 1] + rb_out;
     a.part_in = f.part[(p + 1) & 1] + rb_in;
+#endif
+    a.xres_out = f.xres[p & 1] + rb_out;
     a.xres_in = f.xres[(p + 1) & 1] + rb_in;
     if constexpr (DROP) {      // this step's keep-byte sites, as launch_phases' drop_of gives them to the launch-per-phase kernels
       const mmt_decoder_dropout &Dr = f.drop;
@@ -2170,7 +2198,7 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
         else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
       }
       if (!pipe_phase<DH, PHASE, NH, D, FS, DROP>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li,
-                                                  f.NC <= f.R)) return;
+                                                  f.NC <= f.R, last_phase)) return;
       kv_ready = nx_cluster >= 0;
     }
   }
@@ -2229,7 +2257,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
     embed_pe(pe, a, s);
     const unsigned p_last = (unsigned)(NP * f.a.ph - 1);
     const size_t rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
-    a.part_in = f.part[(p + 1) & 1] + rb_in;
+    a.part_in = f.part[(p + 1) & 1] + rb_in * (FW_ROW_PARTS ? f.a.H : 1);
     a.xres_in = f.xres[(p + 1) & 1] + rb_in;
     if constexpr (DROP) {      // dropout3 of the last layer at the step the head consumes; the positional encoder's at this step
       const size_t Bd = (size_t)a.B * a.d;
