@@ -2496,6 +2496,11 @@ PipeGeom pipe_geom(int L, int H, int NC, int ncu) {
 bool pipe_applies(const mmt_decoder *dec, int NC, int ncu) {
   if (dec_env().no_fused || dec_env().no_pipe || !mfma4_fits(dec)) return false;
   if (dec->d_model != 256 || dec->d_ff != 64 * dec->nhead) return false;
+  // tag generations ("tag bits" above): a hand-off slot is rewritten every 8 phases and a stage may start polling a cluster's
+  // rows 3L phases before they are written, so a slot shows at most 3L/8 + 1 generations in that window - which the
+  // TAG_MASK + 1 tag values must tell apart.  Holds for every L <= MMT_MAX_LAYERS = 8; checked, not assumed.
+  static_assert(3 * MMT_MAX_LAYERS / 8 + 1 <= (int)TAG_MASK + 1, "tag bits too few for MMT_MAX_LAYERS");
+  if (dec->nlayers < 1 || 3 * dec->nlayers / 8 + 1 > (int)TAG_MASK + 1) return false;
   return pipe_geom(dec->nlayers, dec->nhead, NC, ncu).R >= 1;
 }
 
@@ -3059,7 +3064,7 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
 static bool sweep_pipe_static_ok(const mmt_sweep_pipe *a) {
   if (!a) return false;
   if (a->d != 256 || a->H != 8 || a->d_ff != 64 * a->H || a->n_out != 32 || a->n_pos != 2) return false;
-  if (a->nlayers < 1 || a->nlayers > MMT_MAX_LAYERS || 3 * a->nlayers > 25) return false;      // tag generations: see pipe_applies
+  if (a->nlayers < 1 || a->nlayers > MMT_MAX_LAYERS || 3 * a->nlayers / 8 + 1 > (int)TAG_MASK + 1) return false;      // tag generations: see pipe_applies
   if (a->T < 1 || a->T > KMAX || a->ph < 1 || a->ph > KMAX || a->B < 1 || a->B > PIPE_MAX_B) return false;
   return true;
 }

@@ -239,6 +239,40 @@ def test_fused_decoder_is_bit_identical_to_launch_per_phase():
             ops.decoder_status()
 
 
+@pytest.mark.parametrize("nlayers,ph", [(1, 12), (2, 16), (2, 20), (3, 16), (8, 12)])
+def test_pipeline_tag_generations_at_other_depths_and_horizons(nlayers, ph):
+    """The tagged hand-off tells the generations of a slot apart with 2 bits (decoder_cluster.hip, "tag bits"; the host checks
+    3L/8 + 1 <= 4 in pipe_applies).  Depths whose 3L phases per step are NOT a multiple of the 8 slots walk through every
+    (slot, tag) alignment over a long horizon: 1, 2, 3 layers at the longest horizon the pipeline takes (16 keys), the deepest
+    stack (8 layers: 4 generations in the window, the bound itself), and horizon 20 (beyond the 16-key kernels: the persistent
+    kernel must take over, same results).  Bit-identical to the launch-per-phase kernels, and right against the fp64 oracle."""
+    from multimodal_transformer_amd import ops
+    dev = _dev()
+    hp = make_hyperparams("basic", history=8, horizon=ph,
+                          transformer={"nlayers": nlayers, "nhead": 8, "in_dim": 256, "fdim": 512, "output_size": 32})
+    model, reg = _model(hp, dev)
+    apply_recipe(reg.model_dict, seed=nlayers)
+    try:
+        for B in (128, 21):
+            batch = make_batch(B, 8, ph, seed=ph + B)
+            x, x_st, *_ = _to(batch, dev)
+            ops.decoder_select("cluster_launches" if ph <= 16 else "persistent")
+            want = model.predict(x, x_st, None, None, None, ph)[0]
+            ops.decoder_select("cluster_pipeline" if ph <= 16 else "auto")
+            for it in range(4):
+                got = model.predict(x, x_st, None, None, None, ph)[0]
+                assert torch.equal(want, got), (nlayers, ph, B, it)
+            assert ops.decoder_last_path()[0] == (5 if ph <= 16 else 1), ops.decoder_last_path()
+            torch.cuda.synchronize()
+            ops.decoder_status()
+            n = min(B, 12)
+            ref = _oracle_predict(hp, reg, batch, ph, n)
+            node = batch["x"][:n, -1, 0:2][:, None, :]
+            assert rel_err((got[:n].cpu().numpy() - node) / 80.0, (ref - node) / 80.0) <= TOL
+    finally:
+        ops.decoder_select("auto")
+
+
 @pytest.mark.parametrize("form", ["cluster_pipeline", "cluster_fused"])
 def test_fused_decoder_times_out_loudly(form):
     """Fault injection: one workgroup leaves the one-launch decoder early (mmt_debug_decoder_stall), so the workgroups that
