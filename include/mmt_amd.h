@@ -355,6 +355,34 @@ int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *memory, con
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim, int B, int T,
                                 int ph, float *pred_st, float *workspace, const mmt_decoder_dropout *drop, void *stream);
 
+/* ---- the training step's decode that also keeps what the backward reads (round 3) ---------------------------------------------
+ * The autoregressive decode of mmt_decoder_forward[_dropout] on the weight-stationary pipeline kernel, whose stages ALSO write
+ * every decoder activation the backward pass reads - each value is in a stage's registers or LDS at some point of the decode -
+ * so that the training step needs no second, all-steps forward pass over the decoder (mgcvae.py:375-449 run once, as the
+ * reference's autograd tape does).  `stash` is ONE buffer of mmt_decoder_stash_layout.total_floats floats: nlayers blocks of
+ * layer_floats (offsets x .. p2 inside a block) and a tail block at `tail` (offsets t_*).  Rows are step-major (row s * B + b):
+ *   x      (R, d)    input of the layer (layer 0: embedded token + positional encoding, after its dropout)
+ *   qkv    (R, 3d)   self-attention in_proj output   p1 (B, H, ph, ph) its softmax (keys 0..s of query s; before dropout)
+ *   a1     (R, d)    self-attention output           xhat1 / rstd1 / x1: norm1's normalised rows, 1/std, output
+ *   cq     (R, d)    cross-attention query           p2 (B, H, ph, T)   a2 (R, d)   xhat2 / rstd2 / x2: norm2
+ *   f1     (R, d_ff) relu(linear1) after its dropout xhat3 / rstd3: norm3 (its output is the next block's x, or t_x)
+ *   t_x (R, d) output of the last layer, t_ho (R, n_out) output_fc, t_hu / t_hxhat (R, 32) / t_hrstd (R) decoder/MLP's hidden
+ *   layer (ReLU output, normalised rows, 1/std)                                      with R = ph * B.
+ * Values are those the decode itself used (hand-off rows carry their 2 tag bits).  Supported where the pipeline runs
+ * (mmt_decoder_stash_supported: d = 256, 8 heads, d_ff = 512, n_out = 32, decoder/MLP with one 32-wide hidden layer, no
+ * fusion/hist_map, B <= 256, T, ph <= 16, pipeline resident and not disabled on the device); otherwise MMT_EINVAL and the caller
+ * runs the all-steps pass (training.TrainEngine._decoder_steps).  `drop` may be NULL.  No counterpart in the reference. */
+typedef struct {
+  size_t layer_floats, tail, total_floats;
+  size_t x, qkv, a1, xhat1, x1, cq, a2, xhat2, x2, xhat3, f1, rstd1, rstd2, rstd3, p1, p2;
+  size_t t_x, t_ho, t_hu, t_hxhat, t_hrstd;
+} mmt_decoder_stash_layout;
+int mmt_decoder_stash_supported(const mmt_decoder *dec, int B, int T, int ph, int with_dropout);
+int mmt_decoder_stash_layout_of(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out);
+int mmt_decoder_forward_stash(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
+                              const float *mem_feat, int mem_feat_dim, int B, int T, int ph, float *pred_st, float *workspace,
+                              const mmt_decoder_dropout *drop, float *stash, size_t stash_floats, void *stream);
+
 /* ---- reverse-time sweep of the training step as ONE weight-stationary pipeline launch (round 3) -----------------------------
  * Replaces the per-(step, layer) kernel chain of the decoder backward (the autograd of train.py:248 `loss.backward()` through
  * mgcvae.py:432-446's position feedback; training.TrainEngine._sweep here): same inputs (the forward stash), same outputs (every

@@ -63,6 +63,13 @@ class DecoderDropout(C.Structure):
                                             for n in ("attn1", "drop1", "attn2", "drop2", "ff", "drop3")]
 
 
+class DecoderStashLayout(C.Structure):
+    """mmt_decoder_stash_layout (include/mmt_amd.h): offsets, in floats, of the training stash the pipeline decode writes."""
+    FIELDS = ("layer_floats", "tail", "total_floats", "x", "qkv", "a1", "xhat1", "x1", "cq", "a2", "xhat2", "x2", "xhat3", "f1",
+              "rstd1", "rstd2", "rstd3", "p1", "p2", "t_x", "t_ho", "t_hu", "t_hxhat", "t_hrstd")
+    _fields_ = [(n, C.c_size_t) for n in FIELDS]
+
+
 class Cnn(C.Structure):
     _fields_ = [("nconv", C.c_int32), ("in_ch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
                 ("out_ch", C.c_int32 * MMT_MAX_CONV), ("ksize", C.c_int32 * MMT_MAX_CONV),
@@ -165,6 +172,10 @@ SIGNATURES = {
     "mmt_decoder_dropout_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     "mmt_decoder_forward_dropout": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int,
                                               C.c_int, fptr, fptr, C.POINTER(DecoderDropout), C.c_void_p]),
+    "mmt_decoder_stash_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mmt_decoder_stash_layout_of": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int, C.POINTER(DecoderStashLayout)]),
+    "mmt_decoder_forward_stash": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr,
+                                            C.POINTER(DecoderDropout), fptr, C.c_size_t, C.c_void_p]),
     "mmt_sweep_pipe_supported": (C.c_int, [C.POINTER(SweepPipe)]),
     "mmt_sweep_pipe_workspace_floats": (C.c_size_t, [C.POINTER(SweepPipe)]),
     "mmt_sweep_pipe_run": (C.c_int, [C.POINTER(SweepPipe), fptr, C.c_void_p]),

@@ -655,13 +655,23 @@ __device__ __forceinline__ float row32_total(float x0, float x1) {
   t = row_ror_add<1>(t);
   return t;
 }
-template <int CWK>
+// STASH: st_ho = output_fc's rows (n_out wide), st_hu / st_hxhat / st_hrstd = the hidden layer's ReLU output, normalised row and
+// 1/std (32 wide; one hidden layer: mmt_decoder_stash_supported), all at the stash row of the cluster's first agent
+template <int CWK, bool STASH = false>
 __device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na, float *ha, float *hb, float *tok, float *pos,
-                                                const float *cw) {
+                                                const float *cw, float *st_ho = nullptr, float *st_hu = nullptr,
+                                                float *st_hxhat = nullptr, float *st_hrstd = nullptr) {
 #pragma clang fp contract(off)
   const int hs = a.s - 1, lane = lane_id(), r = lane >> 4, c = lane & 15;
   float *cur = ha, *alt = hb;
   float out[2] = {0.f, 0.f};
+  if constexpr (STASH) {
+    if (r < na) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (c + 16 * t < a.n_out) st_ho[(size_t)r * a.n_out + c + 16 * t] = ha[r * LDO + c + 16 * t];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < CHAIN_MAX; ++i) {
     if (i < a.n_chain) {
@@ -723,8 +733,18 @@ __device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na,
         const float rstd = 1.0f / sqrtf(var + MMT_LN_EPS);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const float y = fmaf((out[t] - mu) * rstd, a.chain_ln[i].g[c + 16 * t], a.chain_ln[i].b[c + 16 * t]);
+          const float xh = (out[t] - mu) * rstd;
+          const float y = fmaf(xh, a.chain_ln[i].g[c + 16 * t], a.chain_ln[i].b[c + 16 * t]);
           out[t] = fmaxf(y, 0.f);
+          if constexpr (STASH) {
+            if (i == 0 && r < na) {
+              st_hxhat[(size_t)r * 32 + c + 16 * t] = xh;
+              st_hu[(size_t)r * 32 + c + 16 * t] = out[t];
+            }
+          }
+        }
+        if constexpr (STASH) {
+          if (i == 0 && r < na && c == 0) st_hrstd[r] = rstd;
         }
       }
       alt[r * LDO + c] = out[0];
@@ -1020,9 +1040,12 @@ __device__ __forceinline__ void reduce4_issue(Red4Regs &R, const ClArgs &a, int 
 // as ONE pre-summed part (half the rows for its consumers to load); the forms stay bit-identical.
 // pre_keep (DROP): the row's four keep bytes, already loaded (the pipeline requests them before it polls: a load behind the poll
 // would be a memory round trip on every hop)
-template <int AUX = AUX_PLAIN, bool DROP = false, bool PAIRS = false>
+// STASH (the training step's decode, mmt_decoder_forward_stash): the row's LayerNorm output, normalised row and 1/std also go to
+// st_x / st_xhat / st_rstd (this wave's row of the stash; NULL: not kept)
+template <int AUX = AUX_PLAIN, bool DROP = false, bool PAIRS = false, bool STASH = false>
 __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &a, int cluster, float *xs, int ldx, bool write_res,
-                                               bool tag_rows = true, const unsigned *pre_keep = nullptr) {
+                                               bool tag_rows = true, const unsigned *pre_keep = nullptr, float *st_x = nullptr,
+                                               float *st_xhat = nullptr, float *st_rstd = nullptr) {
   const int row = wave_id(), q = lane_id();
   const bool live = q < (a.d >> 2);
   f32x4 part[PAIRS ? 4 : 8];
@@ -1074,6 +1097,16 @@ __device__ __forceinline__ void reduce4_finish(const Red4Regs &R, const ClArgs &
     if (a.tagged && tag_rows) y = tag4(y, phase_tag(a));       // this phase's input = the next phase's residual rows
     *reinterpret_cast<f32x4 *>(xs + row * ldx + 4 * q) = y;
     if (write_res) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + row) * a.d), (unsigned)q * 16u, y);
+    if constexpr (STASH) {
+      if (st_x) {
+        f32x4 xh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xh[e] = (acc[e] - mu) * rstd;
+        *reinterpret_cast<f32x4 *>(st_x + 4 * q) = y;
+        *reinterpret_cast<f32x4 *>(st_xhat + 4 * q) = xh;
+        if (q == 0) *st_rstd = rstd;
+      }
+    }
   }
 }
 
@@ -1708,7 +1741,23 @@ struct PipeArgs {
   mmt_norm head_ln;                            //   linear2 bias and norm3
   int nlayers, test_stall, R, NHW, NC, pad_;
   mmt_decoder_dropout drop;                    // DROP instantiation only: the training step's keep-byte sites
+  float *stash;                                // STASH instantiation only: the training step's activation stash (stash_off)
 };
+// Layout of the training stash (include/mmt_amd.h, mmt_decoder_stash_layout): one block per layer + a tail block; rows are
+// step-major (row s * B + b), the attention probabilities (B, H, ph, Lk) - the layouts the training kernels read.
+__host__ __device__ __forceinline__ mmt_decoder_stash_layout stash_off(int B, int T, int ph, int d, int dff, int H, int n_out, int nlayers) {
+  const size_t R = (size_t)ph * B, Rd = R * d;
+  mmt_decoder_stash_layout o;
+  o.x = 0, o.qkv = Rd, o.a1 = 4 * Rd, o.xhat1 = 5 * Rd, o.x1 = 6 * Rd, o.cq = 7 * Rd, o.a2 = 8 * Rd, o.xhat2 = 9 * Rd, o.x2 = 10 * Rd;
+  o.xhat3 = 11 * Rd, o.f1 = 12 * Rd;
+  o.rstd1 = o.f1 + R * dff, o.rstd2 = o.rstd1 + R, o.rstd3 = o.rstd2 + R;
+  o.p1 = o.rstd3 + R, o.p2 = o.p1 + (size_t)B * H * ph * ph;
+  o.layer_floats = (o.p2 + (size_t)B * H * ph * T + 63) & ~(size_t)63;
+  o.tail = (size_t)nlayers * o.layer_floats;
+  o.t_x = 0, o.t_ho = Rd, o.t_hu = o.t_ho + R * n_out, o.t_hxhat = o.t_hu + R * 32, o.t_hrstd = o.t_hxhat + R * 32;
+  o.total_floats = o.tail + ((o.t_hrstd + R + 63) & ~(size_t)63);
+  return o;
+}
 constexpr int PIPE_MAXPOS = 16;                // clusters whose last positions a head workgroup keeps in LDS (others: pred_st)
 
 struct PipeLds {
@@ -1899,7 +1948,10 @@ __device__ __forceinline__ bool poll_rows(Red4Regs &R, const ClArgs &a, const fl
 // zeros and meet probabilities that are zeros: no select per key (16 lane masks = 32 spilled SGPRs in this kernel)
 template <int DH, int PHASE, bool ZEROED = false>
 __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const float *t1, int ld1, const float *Ks, const float *Vs,
-                                        float *ps, float *ob, int visit = 0, int att_keep = -1) {
+                                        float *ps, float *ob, int visit = 0, int att_keep = -1, float *st_p = nullptr,
+                                        size_t st_p_stride = 0, float *st_o = nullptr) {
+  // st_p / st_o (training stash): the softmax (before its dropout) of agent ar goes to st_p[ar * st_p_stride + key], the head's
+  // attention output to st_o[ar * d + column]
   constexpr int LDK = DH + 4;
   const int nglob = PHASE == PH_A ? a.s : a.T;
   const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
@@ -1926,6 +1978,7 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
   float p = mx > -INFINITY ? expf(sc - mx) : 0.f;    // a fully masked row yields zeros (reference: undefined / NaN)
   const float sum = row16_sum(p);
   p *= sum > 0.f ? 1.0f / sum : 0.f;
+  if (st_p && ar < na && l16 < nkeys) st_p[(size_t)ar * st_p_stride + l16] = p;
   if (att_keep >= 0 && !masked) p = att_keep ? p * a.ds_att : 0.f;      // dropout on the probabilities (as phase4_body<DROP>)
   ps[lane] = p;
   PSTAMP(visit, 9);
@@ -1959,20 +2012,32 @@ __device__ __forceinline__ void attend4(const ClArgs &a, int na, int pad, const 
   }
 #pragma unroll
   for (int e = 0; e < DPL; ++e) ob[ar * LDO + l16 * DPL + e] = o[e];
+  if (st_o && ar < na) {
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) st_o[(size_t)ar * a.d + l16 * DPL + e] = o[e];
+  }
   PSTAMP(visit, 10);
 }
 
 // One visit of a stage workgroup to one cluster: NH heads / slices starting at g0, weights already in M.
 // kv_ready: M[].kv / pad already hold this visit's K/V cache rows (requested during the previous visit); nx_*: the next visit,
 // whose rows are requested behind this visit's attention (nx_cluster < 0: none, or they are not final yet).
-template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false>
+// STASH: stl = this layer's block of the training stash (stash_off), nlayers the stack's depth
+template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false, bool STASH = false>
 __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, int cluster, int g0, bool loadx, const PipeLds &S,
                                            const PipeSync &ps, MainRegs4<DH, PHASE> (&M)[NH], int &pad, bool kv_ready, int nx_step,
-                                           int nx_cluster, int visit, bool wait_appends = true, bool last_phase = false) {
+                                           int nx_cluster, int visit, bool wait_appends = true, bool last_phase = false,
+                                           float *stl = nullptr, int nlayers = 0) {
   constexpr int AUX = AUX_SC1;
   constexpr int LD1 = 3 * DH + 8, LDK = DH + 4;
   const int d = a.d, ldx = d + MMT_PAD, tid = thread_idx();
   const int a0 = cluster * 4, na = min(4, a.B - a0);
+  mmt_decoder_stash_layout so = {};
+  size_t st_row0 = 0;                 // stash row of the cluster's first agent at this step
+  if constexpr (STASH) {
+    so = stash_off(a.B, a.T, a.ph, d, FS * a.H, a.H, a.n_out, nlayers);
+    st_row0 = (size_t)a.s * a.B + a0;
+  }
   const unsigned tag_out = phase_tag(a), tag_in = tag_of_phase((unsigned)a.prof_idx - 1u);
   PSTAMP(visit, 0);
   PSTAMPC(visit, 12);
@@ -2043,13 +2108,28 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   PSTAMP(visit, 1);
   // ---- 2. input of this sub-layer
   if (red_wave) {
+    // STASH: the slice-0 workgroup keeps the sub-layer's input row (x / x1 / x2) and the LayerNorm that made it (self-attention
+    // stage: the PREVIOUS layer's norm3)
+    float *st_x = nullptr, *st_xhat = nullptr, *st_rstd = nullptr;
+    if constexpr (STASH) {
+      if (g0 == 0 && wave_id() < na) {
+        const size_t row = st_row0 + wave_id();
+        st_x = stl + (PHASE == PH_A ? so.x : PHASE == PH_B ? so.x1 : so.x2) + row * d;
+        float *lnl = PHASE == PH_A ? stl - so.layer_floats : stl;
+        st_xhat = lnl + (PHASE == PH_A ? so.xhat3 : PHASE == PH_B ? so.xhat1 : so.xhat2) + row * d;
+        st_rstd = lnl + (PHASE == PH_A ? so.rstd3 : PHASE == PH_B ? so.rstd1 : so.rstd2) + row;
+      }
+    }
     if (loadx) {
       if (lane_id() < (d >> 2)) {
         *reinterpret_cast<f32x4 *>(S.xs + wave_id() * ldx + 4 * lane_id()) = R.res;
         if (g0 == 0) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + wave_id()) * d), (unsigned)lane_id() * 16u, tag4(R.res, tag_out));
+        if constexpr (STASH) {
+          if (st_x) *reinterpret_cast<f32x4 *>(st_x + 4 * lane_id()) = R.res;
+        }
       }
     } else {
-      reduce4_finish<AUX, DROP>(R, a, cluster, S.xs, ldx, g0 == 0, true, DROP ? &k_red : nullptr);
+      reduce4_finish<AUX, DROP, false, STASH>(R, a, cluster, S.xs, ldx, g0 == 0, true, DROP ? &k_red : nullptr, st_x, st_xhat, st_rstd);
     }
   }
   // K/V cache rows (the self-attention cache was appended by this very workgroup in earlier steps): registers -> staging tiles
@@ -2076,12 +2156,46 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   PSTAMP(visit, 7);
   __syncthreads();
   PSTAMP(visit, 3);
+  if constexpr (STASH) {      // the first linear's result (q|k|v of the head, the heads' cross queries, the hidden slice): waves 2, 3
+    constexpr int C4 = DH / 4;
+    const int i = tid - 128;
+    if constexpr (PHASE == PH_A) {
+      if (i >= 0 && i < 4 * 3 * C4) {
+        const int r = i / (3 * C4), rem = i - r * 3 * C4, part = rem / C4, c4 = rem - part * C4;
+        if (r < na)
+          *reinterpret_cast<f32x4 *>(stl + so.qkv + (st_row0 + r) * 3 * d + part * d + g0 * DH + 4 * c4) =
+              *reinterpret_cast<const f32x4 *>(S.t1 + r * LD1 + part * DH + 4 * c4);
+      }
+    } else if constexpr (PHASE == PH_B) {
+      if (i >= 0 && i < NH * 4 * C4) {
+        const int h = i / (4 * C4), rem = i - h * 4 * C4, r = rem / C4, c4 = rem - r * C4;
+        if (r < na)
+          *reinterpret_cast<f32x4 *>(stl + so.cq + (st_row0 + r) * d + (g0 + h) * DH + 4 * c4) =
+              *reinterpret_cast<const f32x4 *>(S.t1 + (h * 4 + r) * LD1 + 4 * c4);
+      }
+    } else {
+      if (i >= 0 && i < 4 * (FS / 4)) {
+        const int r = i / (FS / 4), c4 = i - r * (FS / 4);
+        if (r < na)
+          *reinterpret_cast<f32x4 *>(stl + so.f1 + (st_row0 + r) * (size_t)(FS * a.H) + g0 * FS + 4 * c4) =
+              *reinterpret_cast<const f32x4 *>(S.t1 + r * LD1 + 4 * c4);
+      }
+    }
+  }
   // ---- 4. attention: wave h serves head g0 + h
   if constexpr (PHASE != PH_C) {
     if (wave_id() < NH) {
       const int h = wave_id();
+      float *st_p = nullptr, *st_o = nullptr;
+      size_t st_ps = 0;
+      if constexpr (STASH) {
+        const int Lk = PHASE == PH_A ? a.ph : a.T;
+        st_ps = (size_t)a.H * a.ph * Lk;
+        st_p = stl + (PHASE == PH_A ? so.p1 : so.p2) + (((size_t)a0 * a.H + g0 + h) * a.ph + a.s) * Lk;
+        st_o = stl + (PHASE == PH_A ? so.a1 : so.a2) + st_row0 * d + (g0 + h) * DH;
+      }
       attend4<DH, PHASE, PIPE_ATT_ZEROED>(a, na, pad_now, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
-                         S.ob + h * 4 * LDO, visit, (DROP && on_att) ? (int)(kb_att & 0xffu) : -1);
+                         S.ob + h * 4 * LDO, visit, (DROP && on_att) ? (int)(kb_att & 0xffu) : -1, st_p, st_ps, st_o);
     } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read back by this workgroup only)
       const int i = tid - 256;
       if (i < na * 2 * (DH / 4)) {
@@ -2122,7 +2236,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   return true;
 }
 
-template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false>
+template <int DH, int PHASE, int NH, int D, int FS, bool DROP = false, bool STASH = false>
 __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0, int replica, const PipeLds &S, const PipeSync &ps) {
   static_assert(PHASE != PH_A || NH == 1, "the K/V cache append serves one head");
   ClArgs a = f.a;
@@ -2197,8 +2311,10 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
         if (m + f.R < f.NC) nx_cluster = m + f.R;
         else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
       }
-      if (!pipe_phase<DH, PHASE, NH, D, FS, DROP>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li,
-                                                  f.NC <= f.R, last_phase)) return;
+      float *stl = nullptr;
+      if constexpr (STASH) stl = f.stash + (size_t)layer * stash_off(a.B, a.T, a.ph, a.d, FS * a.H, a.H, a.n_out, f.nlayers).layer_floats;
+      if (!pipe_phase<DH, PHASE, NH, D, FS, DROP, STASH>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li,
+                                                         f.NC <= f.R, last_phase, stl, f.nlayers)) return;
       kv_ready = nx_cluster >= 0;
     }
   }
@@ -2206,7 +2322,9 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
 
 // The head workgroups: head of the previous step (s > 0) and embedding of the next token, for the clusters
 // replica + R * (j + NHW * i), i = 0, 1, ...  The token rows go to x0buf (tag s & 1), a buffer of their own.
-template <int CPW, bool DROP = false, int CWK = 32>
+// STASH: one more pass (s = ph) that only runs the head of the last step - the stash needs its rows too (the final head launch
+// behind the kernel recomputes the same positions)
+template <int CPW, bool DROP = false, int CWK = 32, bool STASH = false>
 __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j, const PipeLds &S, const PipeSync &ps) {
   ClArgs a = f.a;
   const int d = a.d, ldx = d + MMT_PAD, K16 = d >> 4, tid = thread_idx();
@@ -2248,13 +2366,16 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
   if (tid >= 256)
     for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
       *reinterpret_cast<f32x4 *>(S.xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  mmt_decoder_stash_layout so = {};
+  if constexpr (STASH) so = stash_off(a.B, a.T, a.ph, d, 64 * a.H, a.H, a.n_out, f.nlayers);
 #pragma clang loop unroll(disable)
-  for (int s = 0; s < f.a.ph; ++s) {
+  for (int s = 0; s < f.a.ph + (STASH ? 1 : 0); ++s) {
+    const bool head_only = STASH && s == f.a.ph;
     const unsigned p = (unsigned)(s * NP);           // the phase this step's first stage runs as; the head consumes phase p - 1
     a.s = s;
     a.prof_idx = (int)p;
-    float pe[2];
-    embed_pe(pe, a, s);
+    float pe[2] = {0.f, 0.f};
+    if (!head_only) embed_pe(pe, a, s);
     const unsigned p_last = (unsigned)(NP * f.a.ph - 1);
     const size_t rb_in = (size_t)4 * (((p_last - (p - 1u)) >> 1) & 3u) * f.a.d;
     a.part_in = f.part[(p + 1) & 1] + rb_in * (FW_ROW_PARTS ? f.a.H : 1);
@@ -2263,7 +2384,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
       const size_t Bd = (size_t)a.B * a.d;
       a.dk_red = (f.drop.drop3[f.nlayers - 1] && s > 0) ? f.drop.drop3[f.nlayers - 1] + (size_t)(s - 1) * Bd : nullptr;
       a.ds_red = f.drop.drop3_scale[f.nlayers - 1];
-      a.dk_pe = f.drop.pe ? f.drop.pe + (size_t)s * Bd : nullptr;
+      a.dk_pe = (f.drop.pe && !head_only) ? f.drop.pe + (size_t)s * Bd : nullptr;
       a.ds_pe = f.drop.pe_scale;
     }
     int li = 0;
@@ -2292,12 +2413,33 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
       PSTAMP(s * 4096 + li, 1);
       __syncthreads();
       if (*ps.abort) return;
-      if (red_wave) reduce4_finish<AUX_SC1, DROP>(R, a, m, S.xs, ldx, false, false, DROP ? &k_red : nullptr);
+      const size_t st_row0 = STASH && s > 0 ? (size_t)(s - 1) * a.B + a0 : 0;      // the head works on step s - 1
+      if (red_wave) {
+        float *st_x = nullptr, *st_xhat = nullptr, *st_rstd = nullptr;
+        if constexpr (STASH) {
+          if (wave_id() < na) {
+            float *last = f.stash + so.tail - so.layer_floats;
+            st_x = f.stash + so.tail + so.t_x + (st_row0 + wave_id()) * d;
+            st_xhat = last + so.xhat3 + (st_row0 + wave_id()) * d;
+            st_rstd = last + so.rstd3 + st_row0 + wave_id();
+          }
+        }
+        reduce4_finish<AUX_SC1, DROP, false, STASH>(R, a, m, S.xs, ldx, false, false, DROP ? &k_red : nullptr, st_x, st_xhat, st_rstd);
+      }
       if (s > 0) {
         float *posl = li < PIPE_MAXPOS ? S.pos + li * 64 : nullptr;
         head_step<CPW>(a, 0, a0, na, S.xs, ldx, S.red, S.ha, S.hb, S.tok, wo, sm0, posl, wave_chain);
-        if (wave_chain && wave_id() == 0) head_chain_wave<CWK>(a, a0, na, S.ha, S.hb, S.tok, posl, cw);
+        if (wave_chain && wave_id() == 0) {
+          if constexpr (STASH) {
+            float *tl = f.stash + so.tail;
+            head_chain_wave<CWK, true>(a, a0, na, S.ha, S.hb, S.tok, posl, cw, tl + so.t_ho + st_row0 * a.n_out, tl + so.t_hu + st_row0 * 32,
+                                       tl + so.t_hxhat + st_row0 * 32, tl + so.t_hrstd + st_row0);
+          } else {
+            head_chain_wave<CWK>(a, a0, na, S.ha, S.hb, S.tok, posl, cw);
+          }
+        }
       }
+      if (head_only) continue;        // (uniform: the whole workgroup skips the embedding and its two barriers)
       if (a.tgt || s == 0)
         for (int i = tid; i < na * a.n_in; i += CNT) {
           const int r = i / a.n_in, c = i - r * a.n_in;
@@ -2317,7 +2459,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
   }
 }
 
-template <int DH, int CPW, int D, int FS, bool DROP = false, int CWK = 32>
+template <int DH, int CPW, int D, int FS, bool DROP = false, int CWK = 32, bool STASH = false>
 __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
   extern __shared__ __align__(16) float smem[];
   const PipeLds S = pipe_lds<DH>(smem, f.a.d);
@@ -2330,11 +2472,11 @@ __global__ __launch_bounds__(CNT) void mmt_dec_pipe4_kernel(PipeArgs f) {
   __syncthreads();
   if (rb < f.nlayers * per_layer) {
     const int layer = rb / per_layer, q = rb - layer * per_layer;
-    if (q < H) pipe_stage<DH, PH_A, 1, D, FS, DROP>(f, layer, q, replica, S, ps);
-    else if (q < H + H / 2) pipe_stage<DH, PH_B, 2, D, FS, DROP>(f, layer, 2 * (q - H), replica, S, ps);
-    else pipe_stage<DH, PH_C, 1, D, FS, DROP>(f, layer, q - H - H / 2, replica, S, ps);
+    if (q < H) pipe_stage<DH, PH_A, 1, D, FS, DROP, STASH>(f, layer, q, replica, S, ps);
+    else if (q < H + H / 2) pipe_stage<DH, PH_B, 2, D, FS, DROP, STASH>(f, layer, 2 * (q - H), replica, S, ps);
+    else pipe_stage<DH, PH_C, 1, D, FS, DROP, STASH>(f, layer, q - H - H / 2, replica, S, ps);
   } else {
-    pipe_head<CPW, DROP, CWK>(f, replica, rb - f.nlayers * per_layer, S, ps);
+    pipe_head<CPW, DROP, CWK, STASH>(f, replica, rb - f.nlayers * per_layer, S, ps);
   }
 }
 
@@ -2666,7 +2808,8 @@ size_t mmt_cluster_decoder_extra_floats(const mmt_decoder *dec, int B, int T) {
 
 template <int DH, int CPW, bool M4>
 static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float *part[2], float *xres[2], float *memkv, float *selfkv,
-                         unsigned *sync, int one_launch, const PipeGeom &pg, hipStream_t st, const mmt_decoder_dropout *drop = nullptr) {
+                         unsigned *sync, int one_launch, const PipeGeom &pg, hipStream_t st, const mmt_decoder_dropout *drop = nullptr,
+                         float *stash = nullptr) {
   const bool fused = one_launch != ONE_LAUNCH_NONE;
   const int d = dec->d_model, H = dec->nhead, NC = (B + a.RC - 1) / a.RC, L = dec->nlayers;
   constexpr int LD1 = (3 * DH > 64 ? 3 * DH : 64) + 8;
@@ -2707,6 +2850,10 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
         (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
       }
     }
@@ -2782,9 +2929,13 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         f.NHW = pg.NHW;
         f.NC = NC;
         if (drop) f.drop = *drop;
+        f.stash = stash;
         if constexpr (DH == 32 && CPW == 2) {    // the pipeline is built for the shipped geometry (pipe_geom_ok): d = 256, d_ff / H = 64
           const size_t plds = pipe_lds_floats<32>(256) * sizeof(float);
-          if (pipe_wide_chain(dec, a.tgt != nullptr)) {      // a head linear with 33..64 inputs (fusion/hist_map): the instantiation that stages them
+          if (stash) {                           // (mmt_cluster_decoder_stash_ok: the 32-input chain)
+            if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>), dim3(pg.grid), blk, plds, st, f);
+            else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 32, true>), dim3(pg.grid), blk, plds, st, f);
+          } else if (pipe_wide_chain(dec, a.tgt != nullptr)) {      // a head linear with 33..64 inputs (fusion/hist_map): the instantiation that stages them
             if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>), dim3(pg.grid), blk, plds, st, f);
             else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>), dim3(pg.grid), blk, plds, st, f);
           } else if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true>), dim3(pg.grid), blk, plds, st, f);
@@ -2860,7 +3011,7 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
 }
 
 // The one-launch kernel spins on its siblings: it is only started when the occupancy query says the whole grid is resident.
-static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool drop = false, bool wide = false) {
+static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool drop = false, bool wide = false, bool stash = false) {
   constexpr int DH = 32;
   constexpr int LD1 = 3 * DH + 8;
   const size_t lds = pipe ? pipe_lds_floats<DH>(d) * sizeof(float)
@@ -2868,7 +3019,9 @@ static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool
                              (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
   int per_cu = 0;
   hipError_t e;
-  if (pipe && wide) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>, CNT, lds)
+  if (pipe && stash) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>, CNT, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 32, true>, CNT, lds);
+  else if (pipe && wide) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>, CNT, lds)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>, CNT, lds);
   else if (pipe && drop) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, CNT, lds);
   else if (pipe) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64>, CNT, lds);
@@ -2918,6 +3071,20 @@ extern "C" int mmt_debug_decoder_stall(int on) {
   return MMT_OK;
 }
 
+// The pipeline's STASH instantiation (include/mmt_amd.h: mmt_decoder_forward_stash): static conditions + what the device says now
+bool mmt_cluster_decoder_stash_ok(const mmt_decoder *dec, int B, int T, int ph, bool drop) {
+  if (dec->d_model != 256 || dec->nhead != 8 || dec->d_ff != 512 || dec->n_out != 32 || dec->has_map_fusion) return false;
+  if (dec->head.n_hidden != 1 || dec->head.hidden[0].n != 32 || dec->head.hidden[0].k != 32 || !dec->head.hidden_ln[0].g) return false;
+  if (B < 1 || B > PIPE_MAX_B || T < 1 || T > KMAX || ph < 1 || ph > KMAX) return false;
+  const int dev = cur_dev(), ncu = dev_ncu(dev), NC = (B + 3) / 4;
+  if (cluster_rows(dec, B) != 4 || !pipe_applies(dec, NC, ncu) || g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) return false;
+  const PipeGeom pg = pipe_geom(dec->nlayers, dec->nhead, NC, ncu);
+  return one_launch_fits(true, true, pg.grid, ncu, dec->d_model, drop, false, true);
+}
+void mmt_cluster_decoder_stash_layout(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out) {
+  *out = stash_off(B, T, ph, dec->d_model, dec->d_ff, dec->nhead, dec->n_out, dec->nlayers);
+}
+
 // Same contract as mmt_decoder_forward (arguments already validated there).
 bool mmt_cluster_decoder_dropout_ok(const mmt_decoder *dec, int B) {
   return cluster_rows(dec, B) == 4 && mfma4_fits(dec);
@@ -2926,7 +3093,7 @@ bool mmt_cluster_decoder_dropout_ok(const mmt_decoder *dec, int B) {
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                int allow_fused, void *stream, const mmt_decoder_dropout *drop) {      // 0: launch per phase, 1: fused kernel, 2: pipeline, 3: best
+                                int allow_fused, void *stream, const mmt_decoder_dropout *drop, float *stash) {      // 0: launch per phase, 1: fused kernel, 2: pipeline, 3: best
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d_model, H = dec->nhead, L = dec->nlayers;
   const int RC = cluster_rows(dec, B), NC = (B + RC - 1) / RC;
@@ -2960,9 +3127,12 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   PipeGeom pg = {0, 0, 0, nullptr};
   if (allow_fused != 0 && m4 && !dec_env().no_fused && !g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) {
     if (d == 256 && dec->d_ff == 64 * H) pg = pipe_geom(L, H, NC, ncu);      // the geometry the pipeline kernel is compiled for
-    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d, drop != nullptr, pipe_wide_chain(dec, tgt != nullptr))) one_launch = ONE_LAUNCH_PIPE;
+    if (allow_fused != 1 && !dec_env().no_pipe && pg.R >= 1 && one_launch_fits(true, d > 128, pg.grid, ncu, d, drop != nullptr, pipe_wide_chain(dec, tgt != nullptr), stash != nullptr)) one_launch = ONE_LAUNCH_PIPE;
     else if (allow_fused != 2 && NC * H <= ncu && one_launch_fits(false, d > 128, NC * H, ncu, d)) one_launch = ONE_LAUNCH_FUSED;
   }
+  if (stash && one_launch != ONE_LAUNCH_PIPE)
+    return mmt_set_error(MMT_EINVAL, "mmt_decoder_forward_stash: the pipeline decode does not run here (geometry, occupancy, a device "
+                                     "whose one-launch decode timed out, or a kernel family forced by mmt_decoder_select)");
   const bool fuse_phases = one_launch != ONE_LAUNCH_NONE;
   pg.x0buf = x0buf;
   mmt_note_decoder_path(one_launch == ONE_LAUNCH_PIPE ? MMT_PATH_CLUSTER_PIPELINE : one_launch == ONE_LAUNCH_FUSED ? MMT_PATH_CLUSTER_FUSED
@@ -3049,8 +3219,8 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
   const bool cpw2 = d > 128;
   if (m4) {
     // (CPW still sizes the K-split of the head's small linears, which stay on 16x16x4 tiles)
-    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st, drop)
-                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st, drop);
+    return cpw2 ? launch_phases<32, 2, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st, drop, stash)
+                : launch_phases<32, 1, true>(dec, a, B, ph, part, xres, memkv, selfkv, sync, one_launch, pg, st, drop, stash);
   }
   if (dh == 32)
     return cpw2 ? launch_phases<32, 2, false>(dec, a, B, ph, part, xres, memkv, selfkv, sync, ONE_LAUNCH_NONE, pg, st)

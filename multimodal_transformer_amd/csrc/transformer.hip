@@ -510,7 +510,9 @@ bool mmt_cluster_decoder_dropout_ok(const mmt_decoder *dec, int B);
 int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
-                                int allow_fused, void *stream, const mmt_decoder_dropout *drop);
+                                int allow_fused, void *stream, const mmt_decoder_dropout *drop, float *stash);
+bool mmt_cluster_decoder_stash_ok(const mmt_decoder *dec, int B, int T, int ph, bool drop);
+void mmt_cluster_decoder_stash_layout(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out);
 
 static thread_local int g_last_path = MMT_PATH_NONE;
 void mmt_note_decoder_path(int path) { g_last_path = path; }
@@ -532,7 +534,8 @@ extern "C" size_t mmt_decoder_workspace_floats(const mmt_decoder *dec, int B, in
 static int decoder_forward_impl(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask,
                                 const float *start_pos, const float *map_feat, int map_dim, const float *mem_feat,
                                 int mem_feat_dim, const float *tgt, int B, int T, int ph, float *pred_st,
-                                float *h_out, float *workspace, void *stream, const mmt_decoder_dropout *drop) {
+                                float *h_out, float *workspace, void *stream, const mmt_decoder_dropout *drop,
+                                float *stash = nullptr) {
   if (!dec || !memory || !workspace) return fail(MMT_EINVAL, "mmt_decoder_forward: null pointer");
   const int g_decoder_impl = g_decoder_impl_atomic.load(std::memory_order_relaxed);
   if (B <= 0) return fail(MMT_EINVAL, "mmt_decoder_forward: empty batch (B=%d)", B);
@@ -577,11 +580,14 @@ static int decoder_forward_impl(const mmt_decoder *dec, const float *memory, con
     use_cluster = 2 * ((B + 15) / 16) * dec->nhead <= 5 * ncu;
   }
   if (drop && !cluster_ok) return fail(MMT_EINVAL, "mmt_decoder_forward_dropout: this geometry has no cluster decoder");
-  if (use_cluster || drop)
+  if (stash && (!cluster_ok || g_decoder_impl == MMT_DECODER_PERSISTENT || g_decoder_impl == MMT_DECODER_CLUSTER_LAUNCHES ||
+                g_decoder_impl == MMT_DECODER_CLUSTER_FUSED))
+    return fail(MMT_EINVAL, "mmt_decoder_forward_stash: only the pipeline decode keeps the stash");
+  if (use_cluster || drop || stash)
     return mmt_cluster_decoder_forward(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, tgt, B, T,
                                        ph, pred_st, h_out, workspace,
                                        g_decoder_impl == MMT_DECODER_CLUSTER_LAUNCHES ? 0 : g_decoder_impl == MMT_DECODER_CLUSTER_FUSED ? 1
-                                       : g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE ? 2 : 3, stream, drop);
+                                       : g_decoder_impl == MMT_DECODER_CLUSTER_PIPELINE ? 2 : 3, stream, drop, stash);
   mmt_note_decoder_path(MMT_PATH_PERSISTENT);
   // buf = [ region A | region B ], region B additionally split in two for the map-fusion ping-pong
   const int half = std::max((3 * d + 1) / 2, 2 * (small + MMT_PAD));
@@ -639,6 +645,36 @@ extern "C" int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *
   if (!drop) return fail(MMT_EINVAL, "mmt_decoder_forward_dropout: null mask descriptor");
   return decoder_forward_impl(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, nullptr, B, T, ph, pred_st,
                               nullptr, workspace, stream, drop);
+}
+
+// The training step's decode that also keeps what the backward reads (include/mmt_amd.h).
+static bool stash_static_ok(const mmt_decoder *dec, int B, int T, int ph) {
+  return dec && B > 0 && T > 0 && ph > 0 && mmt_cluster_decoder_supports(dec, 0, true, T, ph) && !dec->has_map_fusion;
+}
+extern "C" int mmt_decoder_stash_supported(const mmt_decoder *dec, int B, int T, int ph, int with_dropout) {
+  if (!stash_static_ok(dec, B, T, ph)) return 0;
+  const int impl = g_decoder_impl_atomic.load(std::memory_order_relaxed);
+  if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_PIPELINE) return 0;
+  return mmt_cluster_decoder_stash_ok(dec, B, T, ph, with_dropout != 0) ? 1 : 0;
+}
+extern "C" int mmt_decoder_stash_layout_of(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out) {
+  if (!out || !stash_static_ok(dec, B, T, ph)) return fail(MMT_EINVAL, "mmt_decoder_stash_layout_of: bad arguments or unsupported geometry");
+  mmt_cluster_decoder_stash_layout(dec, B, T, ph, out);
+  return MMT_OK;
+}
+extern "C" int mmt_decoder_forward_stash(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
+                                         const float *mem_feat, int mem_feat_dim, int B, int T, int ph, float *pred_st,
+                                         float *workspace, const mmt_decoder_dropout *drop, float *stash, size_t stash_floats,
+                                         void *stream) {
+  if (!stash) return fail(MMT_EINVAL, "mmt_decoder_forward_stash: null stash");
+  if (!mmt_decoder_stash_supported(dec, B, T, ph, drop != nullptr))
+    return fail(MMT_EINVAL, "mmt_decoder_forward_stash: not supported for this decoder / batch / device state (mmt_decoder_stash_supported)");
+  mmt_decoder_stash_layout lay;
+  mmt_cluster_decoder_stash_layout(dec, B, T, ph, &lay);
+  if (stash_floats < lay.total_floats)
+    return fail(MMT_EINVAL, "mmt_decoder_forward_stash: stash of %zu floats, need %zu", stash_floats, lay.total_floats);
+  return decoder_forward_impl(dec, memory, pad_mask, start_pos, nullptr, 0, mem_feat, mem_feat_dim, nullptr, B, T, ph, pred_st, nullptr,
+                              workspace, stream, drop, stash);
 }
 
 // ---- the same decode for callers that cannot allocate (include/mmt_amd.h: mmt_decoder_forward_static) ----------------------

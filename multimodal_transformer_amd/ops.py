@@ -624,11 +624,27 @@ def _dropout_desc(dec, sites, B, T, ph):
     return D
 
 
+def decoder_stash_layout(dec: PackedDecoder, B, T, ph):
+    """Offsets (floats) of the training stash that ``decoder_forward(..., stash=)`` fills (mmt_decoder_stash_layout), or None where
+    the geometry has no stash-keeping decode."""
+    lay = _lib.DecoderStashLayout()
+    if _lib.load().mmt_decoder_stash_layout_of(C.byref(dec.desc), B, T, ph, C.byref(lay)) != 0:
+        return None
+    return {n: int(getattr(lay, n)) for n in _lib.DecoderStashLayout.FIELDS}
+
+
+def decoder_stash_supported(dec: PackedDecoder, B, T, ph, with_dropout=False):
+    """Whether the next decode can keep the stash (static geometry AND the device's present state: mmt_decoder_stash_supported)."""
+    return bool(_lib.load().mmt_decoder_stash_supported(C.byref(dec.desc), B, T, ph, int(bool(with_dropout))))
+
+
 def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12, map_feat=None, mem_feat=None,
-                    tgt=None, want_h=False, pred_out=None, dropout=None):
+                    tgt=None, want_h=False, pred_out=None, dropout=None, stash=None):
     """Autoregressive (tgt=None) or teacher-forced decode.  Returns (pred_st (B,ph,n_in) | None, h (B,ph,n_out) | None).
     ``pred_out``: caller-owned (B,ph,n_in) buffer for the autoregressive result (no allocation in this call).
-    ``dropout``: {site: (keep, scale) | None} -- the training step's decode with its keep masks (autoregressive only)."""
+    ``dropout``: {site: (keep, scale) | None} -- the training step's decode with its keep masks (autoregressive only).
+    ``stash``: flat float32 buffer laid out as ``decoder_stash_layout`` says -- the decode also keeps what the backward reads
+    (mmt_decoder_forward_stash; autoregressive only, raises where ``decoder_stash_supported`` is False)."""
     _chk(memory, "memory", (None, None, dec.d_model))
     B, T, _ = memory.shape
     if pad_mask is not None:
@@ -658,6 +674,15 @@ def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12,
     h = torch.empty(B, ph, dec.n_out, dtype=torch.float32, device=dev) if (want_h or tgt is not None) else None
     lib = _lib.load()
     ws = _workspace(lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph), dev)
+    if stash is not None:
+        if tgt is not None or want_h or map_feat is not None:
+            raise MmtError("decoder_forward: the stash-keeping decode is autoregressive, without map fusion")
+        _chk(stash, "stash", (None,))
+        D = _dropout_desc(dec, dropout, B, T, ph) if dropout is not None else None
+        _lib.check(lib.mmt_decoder_forward_stash(C.byref(dec.desc), _ptr(memory), _ptr(pad_mask), _ptr(start_pos), _ptr(mem_feat), mf,
+                                                 B, T, ph, _ptr(pred), _ptr(ws), C.byref(D) if D is not None else None, _ptr(stash),
+                                                 stash.numel(), _stream()), "mmt_decoder_forward_stash")
+        return pred, None
     if dropout is not None:
         if tgt is not None or want_h:
             raise MmtError("decoder_forward: keep masks go with the autoregressive decode only")

@@ -615,15 +615,37 @@ class TrainEngine:
         L = self.Ld
         S.pos = b(ph + 1, B, self.n_pos)
         S.tok = b(ph, B, self.n_pos) if self.teacher_forced else S.pos[:ph]      # decoder input tokens, step-major
-        S.x = [b(ph, B, d) for _ in range(L + 1)]
-        S.qkv = [b(ph, B, 3 * d) for _ in range(L)]
-        S.p1 = [b(B * H * ph * ph) for _ in range(L)]      # (B,H,ph,ph) causal self-attention probabilities
-        S.p2 = [b(B * H * ph * T) for _ in range(L)]       # (B,H,ph,T)
-        for n in ("a1", "x1", "cq", "a2", "x2", "xhat1", "xhat2", "xhat3"):
-            setattr(S, n, [b(ph, B, d) for _ in range(L)])
-        for n in ("rstd1", "rstd2", "rstd3"):
-            setattr(S, n, [b(ph, B) for _ in range(L)])
-        S.f1 = [b(ph, B, fd) for _ in range(L)]
+        # Where the pipeline decode can keep the stash itself (mmt_decoder_forward_stash), the decoder's activations are views
+        # into ONE buffer laid out as the library says; otherwise separate buffers, filled by the all-steps pass (_decoder_steps).
+        lay = self._stash_layout()
+        if lay is not None:
+            S.dec_stash = b(lay["total_floats"])
+            R_ = ph * B
+
+            def view(l, name, n, shape):
+                o = (lay["tail"] if l is None else l * lay["layer_floats"]) + lay[name]
+                return S.dec_stash[o:o + n].view(*shape)
+            S.x = [view(l, "x", R_ * d, (ph, B, d)) for l in range(L)] + [view(None, "t_x", R_ * d, (ph, B, d))]
+            S.qkv = [view(l, "qkv", R_ * 3 * d, (ph, B, 3 * d)) for l in range(L)]
+            S.p1 = [view(l, "p1", B * H * ph * ph, (B * H * ph * ph,)) for l in range(L)]
+            S.p2 = [view(l, "p2", B * H * ph * T, (B * H * ph * T,)) for l in range(L)]
+            for n in ("a1", "x1", "cq", "a2", "x2", "xhat1", "xhat2", "xhat3"):
+                setattr(S, n, [view(l, n, R_ * d, (ph, B, d)) for l in range(L)])
+            for n in ("rstd1", "rstd2", "rstd3"):
+                setattr(S, n, [view(l, n, R_, (ph, B)) for l in range(L)])
+            S.f1 = [view(l, "f1", R_ * fd, (ph, B, fd)) for l in range(L)]
+            self._stash_view = view
+        else:
+            S.dec_stash = None
+            S.x = [b(ph, B, d) for _ in range(L + 1)]
+            S.qkv = [b(ph, B, 3 * d) for _ in range(L)]
+            S.p1 = [b(B * H * ph * ph) for _ in range(L)]      # (B,H,ph,ph) causal self-attention probabilities
+            S.p2 = [b(B * H * ph * T) for _ in range(L)]       # (B,H,ph,T)
+            for n in ("a1", "x1", "cq", "a2", "x2", "xhat1", "xhat2", "xhat3"):
+                setattr(S, n, [b(ph, B, d) for _ in range(L)])
+            for n in ("rstd1", "rstd2", "rstd3"):
+                setattr(S, n, [b(ph, B) for _ in range(L)])
+            S.f1 = [b(ph, B, fd) for _ in range(L)]
         S.mkv = [b(Re, 2 * d) for _ in range(L)]
         S.tmp = b(ph * B, d)
         no = self.n_out
@@ -649,7 +671,14 @@ class TrainEngine:
         else:
             if self.head_tape.k_in != no:
                 raise MmtError("decoder/MLP width does not match output_fc")
-            S.ho = b(ph, B, no)
+            if S.dec_stash is not None:     # output_fc's rows and the head's hidden layer live in the stash's tail block
+                R_, ht = ph * B, self.head_tape
+                S.ho = self._stash_view(None, "t_ho", R_ * no, (ph, B, no))
+                ht.hu[0] = self._stash_view(None, "t_hu", R_ * 32, (ph, B, 32))
+                ht.hxhat[0] = self._stash_view(None, "t_hxhat", R_ * 32, (ph, B, 32))
+                ht.hrstd[0] = self._stash_view(None, "t_hrstd", R_, (ph, B))
+            else:
+                S.ho = b(ph, B, no)
         S.delta = b(ph, B, self.n_pos)
         S.pred = b(B, ph, self.n_pos)                      # autoregressive decode, agent-major (kernel output)
         # decoder gradients, step-major (kept for the deferred weight-gradient GEMMs)
@@ -765,8 +794,11 @@ class TrainEngine:
             # The autoregressive decode itself runs on the fused decoder kernels (positions only, nothing kept); with the
             # tokens known, every activation the backward needs is recomputed for all ph steps at once: causal
             # self-attention over the steps equals the KV-cached recurrence, and ph*B-row GEMMs replace ph B-row ones.
-            self._ar_decode()
-            self._decoder_steps(0, ph)
+            if self._stash_decode_ok():
+                self._ar_decode(stash=True)       # the pipeline decode keeps the stash itself: no second pass
+            else:
+                self._ar_decode()
+                self._decoder_steps(0, ph)
         # loss value and dL/dpos in one pass (mgcvae.py:614-620)
         self.loss.zero_()
         K.l2_loss_bwd(S.pos[1:], self.y_st, S.G[1:], self.loss)
@@ -830,6 +862,34 @@ class TrainEngine:
             self._pdec_fresh = True
         return self._pdec
 
+    stash_decode = True      # let the pipeline decode keep the backward's stash (False: always the all-steps pass)
+
+    def _stash_layout(self):
+        """Layout of the decoder stash where the stash-keeping decode exists for this configuration (Basic / lane, autoregressive,
+        the shipped widths); None otherwise."""
+        if (self.teacher_forced or self.map_mode or torch.device(self.device).type != "cuda" or len(self.head_tape_shape()) != 1
+                or self.head_tape_shape()[0] != 32):
+            return None
+        lay = ops.decoder_stash_layout(self._packed_decoder(), self.B, self.T, self.ph)
+        self.__dict__.pop("_pdec_fresh", None)       # (packed at construction: the first decode re-packs the then-current weights)
+        return lay
+
+    def head_tape_shape(self):
+        """widths of decoder/MLP's hidden layers"""
+        out, i = [], 0
+        while hasattr(self.head.layer_seq, f"lmlp_{i}"):
+            out.append(getattr(self.head.layer_seq, f"lmlp_{i}")[0].weight.shape[0])
+            i += 1
+        return out
+
+    def _stash_decode_ok(self):
+        """Per call (the device's state can change: a one-launch decode that timed out disables the pipeline)."""
+        if not self.stash_decode or self.s.dec_stash is None:
+            return False
+        if self.drop.active and not self._ar_decode_takes_masks():
+            return False
+        return ops.decoder_stash_supported(self._packed_decoder(), self.B, self.T, self.ph, self.drop.active)
+
     def _ar_decode_takes_masks(self):
         """Whether the inference decoder kernels can apply this step's keep masks (mmt_decoder_forward_dropout)."""
         ok = self.__dict__.get("_ar_masks_ok")
@@ -838,7 +898,7 @@ class TrainEngine:
                                                   ops.decoder_dropout_supported(self._packed_decoder(), self.B, self.T, self.ph))
         return ok
 
-    def _ar_decode(self):
+    def _ar_decode(self, stash=False):
         """pos[1:] <- the 12-step autoregressive decode of the current parameters (mgcvae.py:375-449) on the fused
         decoder kernels, from the encoder output and start token already in the stash; with dropout active, on the
         launch-per-phase cluster kernels reading this step's keep masks."""
@@ -858,7 +918,8 @@ class TrainEngine:
             sites = {n: v for n, v in self.drop.view.items() if n.startswith("dec")}
         ops.decoder_forward(self._pdec, S.eh[self.Le].view(self.B, self.T, self.d), S.pad, start_pos=S.pos[0], ph=self.ph,
                             map_feat=S.enc_map_used if self.map_mode else None,
-                            mem_feat=S.enc_lane[:, 0, :].contiguous() if self.lane_mode else None, pred_out=S.pred, dropout=sites)
+                            mem_feat=S.enc_lane[:, 0, :].contiguous() if self.lane_mode else None, pred_out=S.pred, dropout=sites,
+                            stash=S.dec_stash if stash else None)
         S.pos[1:].copy_(S.pred.permute(1, 0, 2))
 
     # ------------------------------------------------------------------ backward

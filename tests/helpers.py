@@ -91,3 +91,21 @@ def check_post_step(p_new, post_ref, grad_ref, lr, tol=1e-4):
     ok_solid = (not solid.any()) or float(np.max(err[solid] / np.maximum(np.abs(post_ref[solid]), floor))) <= tol
     ok_noise = solid.all() or float(np.max(err[~solid])) <= 2.1 * lr
     return ok_solid and ok_noise, float(err.max())
+
+
+def relu_flips(eng_a, eng_b):
+    """Hidden units (decoder feed-forward, decoder/MLP hidden layer) that are active in one engine's forward stash and inactive in
+    the other's: (count, largest activation among them).  Two fp32 forwards that differ by rounding put a unit whose pre-activation
+    is within rounding of 0 on different sides of the ReLU; the backward then gates one (agent, step) contribution of one weight
+    row differently - a discontinuity of the function, not an error of either evaluation.  The training tests use this to tell
+    that case from a wrong gradient: with no flipped unit the strict element-wise tolerance applies."""
+    import torch
+    n, mx = 0, 0.0
+    pairs = [(a, b) for a, b in zip(eng_a.s.f1, eng_b.s.f1)] + [(a, b) for a, b in zip(eng_a.head_tape.hu, eng_b.head_tape.hu)]
+    for a, b in pairs:
+        f = (a > 0) != (b > 0)
+        k = int(f.sum())
+        if k:
+            n += k
+            mx = max(mx, float(torch.maximum(a[f].abs().max(), b[f].abs().max())))
+    return n, mx

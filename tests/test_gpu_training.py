@@ -463,9 +463,17 @@ def test_lane_cnn_step_matches_reference(tiny):
             assert ok, (key, e)
 
 
-def test_full_config_step_matches_reference_gradient_norms():
+@pytest.mark.parametrize("stash_decode", [False, True])
+def test_full_config_step_matches_reference_gradient_norms(stash_decode):
     """BASELINE config 2 per-GPU shard (B=128, T=9, ph=12, 8.0 M parameters): loss, per-parameter gradient norms
-    and the post-AdamW weight checksums of the reference."""
+    and the post-AdamW weight checksums of the reference.  stash_decode = False: the backward reads a stash recomputed by the
+    all-steps pass (plain fp32 rounding): FULL_TOL.  True (the default since round 3): the stash the pipeline decode wrote - the
+    activations the decode itself used, whose hand-off rows carry 2 tag bits (<= 3 ulp each, about 4x the rounding noise per hop);
+    where no hidden unit lands on the other side of its ReLU than in the all-steps stash (helpers.relu_flips) the same FULL_TOL
+    x 3 holds element-wise (the far end of the backward chain, the encoder's input_fc, shows 1.6e-4 of the RMS); where one does
+    (this batch: one unit of layer 2, activation < 1e-5), the gradients that unit feeds are judged by their norms only.
+    Loss, positions and the post-step parameters are the same bits / within the same bounds in both."""
+    tol = FULL_TOL * (3 if stash_decode else 1)
     from multimodal_transformer_amd import training
     from multimodal_transformer_amd.weights import checksum
     dev = _dev()
@@ -475,17 +483,33 @@ def test_full_config_step_matches_reference_gradient_norms():
     set_weights(reg.model_dict, False, z)
     batch = batch_for("basic", False)
     x_st, y_st = torch.from_numpy(batch["x_st"]).to(dev), torch.from_numpy(batch["y_st"]).to(dev)
+    flips = (0, 0.0)
+    if stash_decode:      # which units differ between the two stashes (before the optimizer moves the weights)
+        pair = []
+        for keep in (False, True):
+            e = training.TrainEngine(model, B, x_st.shape[1], ph, dropout=False)
+            e.stash_decode = keep
+            e.set_batch(x_st, y_st)
+            e.forward()
+            pair.append(e)
+        flips = helpers.relu_flips(*pair)
+        assert flips[1] <= 1e-5, flips
+        print("units on different sides of their ReLU in the two stashes:", flips)
+        del pair
     tr = training.Trainer(model, B, x_st.shape[1], ph, use_graph=True)
+    tr.engine.stash_decode = stash_decode
     loss = tr.step(x_st, y_st)
+    assert tr.engine._stash_decode_ok() == stash_decode
     assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
     for name, g in tr.engine.grad_by_name.items():
         want = meta["grad_norms"][name]
         got = float(g.double().norm())
-        assert abs(got - want) <= FULL_TOL * want + 1e-9, (name, got, want)
+        assert abs(got - want) <= tol * want + 1e-9, (name, got, want)
         # element-wise on the first 256 elements of every gradient; floor = the tensor's RMS from its golden norm
         head = z["gradhead::" + name]
         rms = want / np.sqrt(g.numel())
-        assert rel_err(g.reshape(-1)[:256].cpu().numpy(), head, floor=rms + 1e-30) <= FULL_TOL, name
+        e = rel_err(g.reshape(-1)[:256].cpu().numpy(), head, floor=rms + 1e-30)
+        assert e <= (tol if flips[0] == 0 else 1e-2), (name, e, flips)
     for name, mod in reg.model_dict.items():
         for pn, p in mod.named_parameters():
             key = f"{name}.{pn}"
@@ -499,8 +523,8 @@ def test_full_config_step_matches_reference_gradient_norms():
         assert abs(after[name]["abs_sum"] - c["abs_sum"]) <= 1e-5 * c["abs_sum"], name
 
 
-@pytest.mark.parametrize("mode", ["basic", "lane_cnn"])
-def test_full_size_gradients_against_the_fp64_oracle(capsys, mode):
+@pytest.mark.parametrize("mode,stash_decode", [("basic", False), ("lane_cnn", False), ("basic", True), ("lane_cnn", True)])
+def test_full_size_gradients_against_the_fp64_oracle(capsys, mode, stash_decode):
     """Whose error is the full-size gradient gap?  B=128, T=9, ph=12, 6+6 layers, dropout off: the fp64 autograd
     of the reference-form oracle (stock torch.nn modules in double precision, full recompute per AR step) is the arbiter; the
     HIP step's gradients AND the reference's own fp32 autograd (golden ``gradhead::*``, first 256 elements of every gradient,
@@ -519,8 +543,10 @@ def test_full_size_gradients_against_the_fp64_oracle(capsys, mode):
     batch = batch_for(mode, False)
     c = {k: torch.from_numpy(v) for k, v in batch.items()}
     eng = training.TrainEngine(model, B, c["x_st"].shape[1], ph, dropout=False)
+    eng.stash_decode = stash_decode
     eng.set_batch(c["x_st"].to(dev), c["y_st"].to(dev), lanes=c["lanes"].to(dev) if "lanes" in c else None)
     loss = float(eng.forward())
+    assert eng._stash_decode_ok() == stash_decode
     eng.backward()
     torch.cuda.synchronize()
     ref = ReferenceFormModel(hp)
@@ -540,22 +566,33 @@ def test_full_size_gradients_against_the_fp64_oracle(capsys, mode):
     assert abs(loss - float(want_loss)) <= 2e-6 * abs(float(want_loss))
     assert abs(float(z["train_loss"]) - float(want_loss)) <= 2e-6 * abs(float(want_loss))
     worst_hip, worst_gold, worst_l2 = (0.0, None), (0.0, None), (0.0, None)
+    medians = []
     for name, g in eng.grad_by_name.items():
         w = want[name].numpy()
         rms = float(np.sqrt(np.mean(w * w))) + 1e-30
         e_hip = rel_err(g.cpu().numpy(), w)
+        medians.append(float(np.median(np.abs(g.cpu().numpy().astype(np.float64) - w))) / rms)
         worst_l2 = max(worst_l2, (float(np.linalg.norm(g.cpu().numpy().astype(np.float64) - w) / (np.linalg.norm(w) + 1e-30)), name))
         e_gold = rel_err(z["gradhead::" + name], w.reshape(-1)[:256], floor=rms)
         e_hip_head = rel_err(g.reshape(-1)[:256].cpu().numpy(), w.reshape(-1)[:256], floor=rms)
         worst_hip = max(worst_hip, (e_hip, name))
         worst_gold = max(worst_gold, (e_gold, name + f" (HIP on the same 256 elements: {e_hip_head:.2e})"))
     with capsys.disabled():
-        print(f"\nfull-size {mode} gradients vs the fp64 oracle (RMS floor): HIP worst {worst_hip[0]:.3e} at {worst_hip[1]}; "
+        print(f"\nfull-size {mode} gradients vs the fp64 oracle (RMS floor), stash from the "
+              f"{'pipeline decode' if stash_decode else 'all-steps pass'}: median element {np.median(medians):.2e}, worst tensor's median "
+              f"{max(medians):.2e}; HIP worst {worst_hip[0]:.3e} at {worst_hip[1]}; "
               f"reference fp32 autograd (golden heads) worst {worst_gold[0]:.3e} at {worst_gold[1]}; "
               f"HIP worst relative L2 error of a whole gradient {worst_l2[0]:.3e} at {worst_l2[1]}")
     # Basic: every gradient within 1e-4 of fp64, element-wise and as a whole.  Lane_encoding_CNN: an fp32 forward puts a few hidden
     # units on the other side of a ReLU than fp64 does (one (agent, step) contribution of one weight row then differs: 9e-3 of the
     # RMS on a handful of elements of linear1.weight, 1.4e-4 on that gradient as a whole) -- a property of fp32 forwards
+    # Stash written by the pipeline decode (the default since round 3): the hand-off rows' tag bits make the forward's rounding noise
+    # about 4x larger, so more units sit on the other side of a ReLU than in fp64 (Basic now shows one too: 5.6e-3 on single elements,
+    # 1.0e-4 on that gradient as a whole) and the far end of the backward chain carries up to 2e-4: 3e-4 on whole gradients.
+    if stash_decode:
+        assert worst_l2[0] <= 3e-4, worst_l2
+        assert max(medians) <= 3e-5, max(medians)
+        return
     assert worst_l2[0] <= (1e-4 if mode == "basic" else 3e-4), worst_l2        # (lane_cnn: 1.4e-4 observed, ReLU-boundary units)
     if mode == "basic":
         assert worst_hip[0] <= 1e-4, worst_hip
@@ -969,3 +1006,91 @@ def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B, dropout):
         worst = max(worst, (e, name))
         assert e <= 1e-4, (name, e)
     print("pipeline sweep vs launch-per-kernel sweep: worst relative error", worst)
+
+
+def _forward_stash(eng):
+    S, ht = eng.s, eng.head_tape
+    out = {"pos": S.pos}
+    for l in range(eng.Ld):
+        for n in ("x", "qkv", "p1", "a1", "xhat1", "rstd1", "x1", "cq", "p2", "a2", "xhat2", "rstd2", "x2", "f1", "xhat3", "rstd3"):
+            out[f"{n}[{l}]"] = getattr(S, n)[l]
+    out[f"x[{eng.Ld}]"] = S.x[eng.Ld]
+    out.update({"ho": S.ho, "hu": ht.hu[0], "hxhat": ht.hxhat[0], "hrstd": ht.hrstd[0]})
+    return {k: v.detach().clone() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("mode,B,dropout", [("basic", 128, False), ("basic", 37, False), ("lane_cnn", 64, False), ("basic", 200, False),
+                                             ("basic", 128, True), ("lane_cnn", 29, True), ("basic", 3, True)])
+def test_stash_keeping_decode_matches_the_all_steps_pass(mode, B, dropout):
+    """mmt_decoder_forward_stash (the pipeline decode whose stages also write what the backward reads) against the decode + all-steps
+    recomputation it replaces: same positions bit for bit (same decode arithmetic), every stash tensor in forward order (the first one
+    that differs names the stage), then every gradient.  The all-steps pass sums in other orders and carries no tag bits: 1e-4
+    on the stash (observed 5e-6); gradients: see the comment at their check."""
+    from multimodal_transformer_amd import ops, training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _dev()
+    b = make_batch(B, 8, 12, seed=13, with_lanes=(mode == "lane_cnn"))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    res = []
+    for keep in (False, True):
+        hp = make_hyperparams(mode, history=8, horizon=12)
+        if dropout:
+            from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+            hp["autoregressive"] = True
+            reg = ModelRegistrar("/tmp", dev)
+            model = MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, [])
+        else:
+            model, reg = _model(hp, dev)
+        apply_recipe(reg.model_dict, seed=6)
+        eng = training.TrainEngine(model, B, 9, 12, dropout=None if dropout else False, seed=7)
+        assert eng.drop.active == dropout
+        assert eng.s.dec_stash is not None
+        eng.stash_decode = keep
+        eng.set_batch(t["x_st"], t["y_st"], lanes=t.get("lanes"))
+        for _ in range(2):      # twice: the second pass overwrites a stash that is already filled (same seed step: same masks)
+            eng.seed(7, 0)
+            loss = float(eng.forward())
+        assert eng._stash_decode_ok() == keep
+        fwd = _forward_stash(eng)
+        eng.backward()
+        torch.cuda.synchronize()
+        ops.decoder_status()
+        res.append((loss, fwd, {k: v.clone() for k, v in eng.grad_by_name.items()}))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1]["pos"], res[1][1]["pos"])
+    worst = (-1.0, "")
+    for name in res[0][1]:
+        want, got = res[0][1][name].cpu().numpy(), res[1][1][name].cpu().numpy()
+        assert np.isfinite(got).all(), name
+        e = rel_err(got, want)
+        worst = max(worst, (e, name))
+        assert e <= 1e-4, (name, e)
+    # Gradients: two fp32 evaluations from stashes that differ by rounding (5e-6).  Where every hidden unit is on the same side of its
+    # ReLU in both stashes the gradients agree to 1e-4 element-wise (observed 6e-6).  A unit within rounding of the boundary that
+    # is on in one and off in the other (activation < 1e-5; the fp64 arbiter test meets the same against exact arithmetic) gates
+    # one (agent, step) contribution differently: single elements of linear1's gradient move by up to 1e-1 of the RMS, whole
+    # tensors by up to 2e-3 (observed 9e-2 / 1.7e-3) - then only those looser bounds apply.
+    nflip, vflip = 0, 0.0
+    for name in res[0][1]:
+        if name.startswith("f1[") or name == "hu":
+            a, b_ = res[0][1][name], res[1][1][name]
+            f = (a > 0) != (b_ > 0)
+            if int(f.sum()):
+                nflip += int(f.sum())
+                vflip = max(vflip, float(torch.maximum(a[f].abs().max(), b_[f].abs().max())))
+    assert vflip <= 1e-5, (nflip, vflip)
+    worst_g, worst_l2 = (-1.0, ""), (-1.0, "")
+    for name, g in res[1][2].items():
+        got, want = g.double().cpu().numpy(), res[0][2][name].double().cpu().numpy()
+        e = rel_err(got, want)
+        l2 = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+        worst_g, worst_l2 = max(worst_g, (e, name)), max(worst_l2, (l2, name))
+        if nflip == 0:
+            assert e <= 1e-4, (name, e)
+        else:
+            assert l2 <= 2e-3 and e <= 1e-1, (name, l2, e, nflip)
+    print("units on different sides of their ReLU:", nflip, "largest activation among them", vflip)
+    print("stash-keeping decode vs all-steps pass: worst relative error of a stash tensor", worst, "of a gradient: L2", worst_l2,
+          "element-wise", worst_g)
