@@ -366,22 +366,25 @@ int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *memory, con
  *   a1     (R, d)    self-attention output           xhat1 / rstd1 / x1: norm1's normalised rows, 1/std, output
  *   cq     (R, d)    cross-attention query           p2 (B, H, ph, T)   a2 (R, d)   xhat2 / rstd2 / x2: norm2
  *   f1     (R, d_ff) relu(linear1) after its dropout xhat3 / rstd3: norm3 (its output is the next block's x, or t_x)
- *   t_x (R, d) output of the last layer, t_ho (R, n_out) output_fc, t_hu / t_hxhat (R, 32) / t_hrstd (R) decoder/MLP's hidden
+ *   t_x (R, d) output of the last layer, t_ho (R, ho_ld) output_fc [map configurations: cat[output_fc, encoded map], ho_ld =
+ *   n_out + map_dim, and t_u (R, n_out) = fusion/hist_map of it], t_hu / t_hxhat (R, 32) / t_hrstd (R) decoder/MLP's hidden
  *   layer (ReLU output, normalised rows, 1/std)                                      with R = ph * B.
  * Values are those the decode itself used (hand-off rows carry their 2 tag bits).  Supported where the pipeline runs
- * (mmt_decoder_stash_supported: d = 256, 8 heads, d_ff = 512, n_out = 32, decoder/MLP with one 32-wide hidden layer, no
- * fusion/hist_map, B <= 256, T, ph <= 16, pipeline resident and not disabled on the device); otherwise MMT_EINVAL and the caller
+ * (mmt_decoder_stash_supported: d = 256, 8 heads, d_ff = 512, n_out = 32, decoder/MLP with one 32-wide hidden layer,
+ * fusion/hist_map absent or a single Linear of <= 64 inputs, B <= 256, T, ph <= 16, pipeline resident and not disabled on the device); otherwise MMT_EINVAL and the caller
  * runs the all-steps pass (training.TrainEngine._decoder_steps).  `drop` may be NULL.  No counterpart in the reference. */
 typedef struct {
   size_t layer_floats, tail, total_floats;
   size_t x, qkv, a1, xhat1, x1, cq, a2, xhat2, x2, xhat3, f1, rstd1, rstd2, rstd3, p1, p2;
   size_t t_x, t_ho, t_hu, t_hxhat, t_hrstd;
+  size_t t_u, ho_ld;      /* map configurations: fusion/hist_map's output (R, n_out); row width of t_ho (n_out, or n_out + map_dim) */
 } mmt_decoder_stash_layout;
-int mmt_decoder_stash_supported(const mmt_decoder *dec, int B, int T, int ph, int with_dropout);
-int mmt_decoder_stash_layout_of(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out);
+int mmt_decoder_stash_supported(const mmt_decoder *dec, int map_dim, int B, int T, int ph, int with_dropout);
+int mmt_decoder_stash_layout_of(const mmt_decoder *dec, int map_dim, int B, int T, int ph, mmt_decoder_stash_layout *out);
 int mmt_decoder_forward_stash(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
-                              const float *mem_feat, int mem_feat_dim, int B, int T, int ph, float *pred_st, float *workspace,
-                              const mmt_decoder_dropout *drop, float *stash, size_t stash_floats, void *stream);
+                              const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim, int B, int T, int ph,
+                              float *pred_st, float *workspace, const mmt_decoder_dropout *drop, float *stash, size_t stash_floats,
+                              void *stream);
 
 /* ---- reverse-time sweep of the training step as ONE weight-stationary pipeline launch (round 3) -----------------------------
  * Replaces the per-(step, layer) kernel chain of the decoder backward (the autograd of train.py:248 `loss.backward()` through
@@ -429,6 +432,14 @@ typedef struct {
   float *poison;                          /* 1 float: NaN when the sweep gave up (the step's loss / optimizer guard), may be NULL */
   const uint8_t *k_pe;                    /* PositionalEncoding.dropout keep bytes (ph,B,d) or NULL */
   float s_pe, pad2_;
+  /* Map configurations (mgcvae.py:438-443): decoder/MLP's input is fusion/hist_map(cat[output_fc(x), encoded_map]), here a single
+   * Linear (n_out + map_dim -> n_out; fusion_hist_map_layer = 1).  w_fuse = its weight (n_out, n_out + map_dim), natural layout, or
+   * NULL (no fusion).  With it: h_gu receives the gradient at the fusion's output (ph,B,n_out) and h_gho the gradient at the
+   * whole concatenation, rows gho_ld = n_out + map_dim wide (its first n_out columns are the gradient at output_fc's output,
+   * the rest the per-step gradient at the encoded map); without it gho_ld = n_out and h_gu is not written. */
+  const float *w_fuse;
+  float *h_gu;
+  int gho_ld, map_dim;
 } mmt_sweep_pipe;
 int mmt_sweep_pipe_supported(const mmt_sweep_pipe *args);
 size_t mmt_sweep_pipe_workspace_floats(const mmt_sweep_pipe *args);

@@ -66,7 +66,7 @@ class DecoderDropout(C.Structure):
 class DecoderStashLayout(C.Structure):
     """mmt_decoder_stash_layout (include/mmt_amd.h): offsets, in floats, of the training stash the pipeline decode writes."""
     FIELDS = ("layer_floats", "tail", "total_floats", "x", "qkv", "a1", "xhat1", "x1", "cq", "a2", "xhat2", "x2", "xhat3", "f1",
-              "rstd1", "rstd2", "rstd3", "p1", "p2", "t_x", "t_ho", "t_hu", "t_hxhat", "t_hrstd")
+              "rstd1", "rstd2", "rstd3", "p1", "p2", "t_x", "t_ho", "t_hu", "t_hxhat", "t_hrstd", "t_u", "ho_ld")
     _fields_ = [(n, C.c_size_t) for n in FIELDS]
 
 
@@ -132,7 +132,7 @@ class SweepPipe(C.Structure):
                [("layer", SweepLayer * MMT_MAX_LAYERS)] + \
                [(n, fptr) for n in ("G", "gx0", "w_in", "w_hout", "h_gamma", "w_h0", "w_ofc", "h_hu", "h_xhat", "h_rstd", "h_ghum",
                                     "h_ghz", "h_gho", "poison", "k_pe")] + \
-               [("s_pe", C.c_float), ("pad2_", C.c_float)]
+               [("s_pe", C.c_float), ("pad2_", C.c_float), ("w_fuse", fptr), ("h_gu", fptr), ("gho_ld", C.c_int32), ("map_dim", C.c_int32)]
 
 
 class LnGradJob(C.Structure):
@@ -172,10 +172,10 @@ SIGNATURES = {
     "mmt_decoder_dropout_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int]),
     "mmt_decoder_forward_dropout": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int,
                                               C.c_int, fptr, fptr, C.POINTER(DecoderDropout), C.c_void_p]),
-    "mmt_decoder_stash_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int, C.c_int]),
-    "mmt_decoder_stash_layout_of": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int, C.POINTER(DecoderStashLayout)]),
-    "mmt_decoder_forward_stash": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, C.c_int, C.c_int, C.c_int, fptr, fptr,
-                                            C.POINTER(DecoderDropout), fptr, C.c_size_t, C.c_void_p]),
+    "mmt_decoder_stash_supported": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mmt_decoder_stash_layout_of": (C.c_int, [C.POINTER(Decoder), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DecoderStashLayout)]),
+    "mmt_decoder_forward_stash": (C.c_int, [C.POINTER(Decoder), fptr, fptr, fptr, fptr, C.c_int, fptr, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            fptr, fptr, C.POINTER(DecoderDropout), fptr, C.c_size_t, C.c_void_p]),
     "mmt_sweep_pipe_supported": (C.c_int, [C.POINTER(SweepPipe)]),
     "mmt_sweep_pipe_workspace_floats": (C.c_size_t, [C.POINTER(SweepPipe)]),
     "mmt_sweep_pipe_run": (C.c_int, [C.POINTER(SweepPipe), fptr, C.c_void_p]),

@@ -630,6 +630,12 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
   float w0c[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) w0c[k] = bl1(mk_rsrc(A.w_h0), (red_wave && c < NO && k < NO) ? (unsigned)(k * NO + c) * 4u : OOB);
+  // map configurations: lane c' < n_out + map_dim (<= 64) owns column c' of fusion/hist_map's Linear: W_f[:, c']
+  const bool fused_head = A.w_fuse != nullptr;
+  const int GL = A.gho_ld;
+  float wfc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) wfc[k] = bl1(mk_rsrc(A.w_fuse), (fused_head && red_wave && lane < GL && k < NO) ? (unsigned)(k * GL + lane) * 4u : OOB);
   for (int i = tid; i < 2 * 4 * LD1; i += CNT) S.t1[i] = 0.f;
   __syncthreads();
   // head visit sp = 0 .. ph: sp < ph opens step s = ph - 1 - sp; sp > 0 first closes step s + 1
@@ -720,19 +726,28 @@ __device__ __forceinline__ void bwd_head(const BwdPipeArgs &f, int replica, int 
           const float inv_n = 1.0f / (float)NO;
           const float m1 = wave64_total(gg) * inv_n, m2 = wave64_total(gg * hxh) * inv_n;
           const float ghz = (lane < 32 && c < NO) ? hrs * (gg - m1 - hxh * m2) : 0.f;
-          float gho = 0.f;
+          float gho = 0.f;           // gradient at decoder/MLP's input
 #pragma unroll
           for (int k = 0; k < 32; ++k)
             gho = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ghz), k)), w0c[k], gho);
-          if (lane < 32 && c < NO) {
-            S.t1[wv * LD1 + c] = mine ? gho : 0.f;
-            if (mine) {
-              const size_t o = ((size_t)s * B + ag) * NO + c;
-              A.h_ghum[o] = ghum;
-              A.h_ghz[o] = ghz;
-              A.h_gho[o] = gho;
-            }
+          if (lane < 32 && c < NO && mine) {
+            const size_t o = ((size_t)s * B + ag) * NO + c;
+            A.h_ghum[o] = ghum;
+            A.h_ghz[o] = ghz;
           }
+          if (fused_head) {          // ... which is fusion/hist_map's output: one more Linear back to cat[output_fc(x), encoded_map]
+            const float gu = (lane < 32 && c < NO) ? gho : 0.f;
+            if (lane < 32 && c < NO && mine) A.h_gu[((size_t)s * B + ag) * NO + c] = gu;
+            float gc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+              gc = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gu), k)), wfc[k], gc);
+            if (lane < GL && mine) A.h_gho[((size_t)s * B + ag) * GL + lane] = gc;
+            gho = gc;                // lanes < n_out: the gradient at output_fc's output
+          } else if (lane < 32 && c < NO && mine) {
+            A.h_gho[((size_t)s * B + ag) * NO + c] = gho;
+          }
+          if (lane < 32 && c < NO) S.t1[wv * LD1 + c] = mine ? gho : 0.f;
         }
       }
       PSTAMP(visit, 3);

@@ -657,19 +657,22 @@ __device__ __forceinline__ float row32_total(float x0, float x1) {
 }
 // STASH: st_ho = output_fc's rows (n_out wide), st_hu / st_hxhat / st_hrstd = the hidden layer's ReLU output, normalised row and
 // 1/std (32 wide; one hidden layer: mmt_decoder_stash_supported), all at the stash row of the cluster's first agent
+// (map configurations: st_ho rows are cat[output_fc, encoded map], ho_ld wide, and st_u = fusion/hist_map's output - the chain's
+// first linear, which has no LayerNorm)
 template <int CWK, bool STASH = false>
 __device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na, float *ha, float *hb, float *tok, float *pos,
                                                 const float *cw, float *st_ho = nullptr, float *st_hu = nullptr,
-                                                float *st_hxhat = nullptr, float *st_hrstd = nullptr) {
+                                                float *st_hxhat = nullptr, float *st_hrstd = nullptr, float *st_u = nullptr) {
 #pragma clang fp contract(off)
   const int hs = a.s - 1, lane = lane_id(), r = lane >> 4, c = lane & 15;
   float *cur = ha, *alt = hb;
   float out[2] = {0.f, 0.f};
   if constexpr (STASH) {
     if (r < na) {
+      const int ho_ld = a.n_out + (a.has_map_fusion ? a.map_dim : 0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (c + 16 * t < a.n_out) st_ho[(size_t)r * a.n_out + c + 16 * t] = ha[r * LDO + c + 16 * t];
+      for (int t = 0; t < CWK / 16; ++t)
+        if (c + 16 * t < ho_ld) st_ho[(size_t)r * ho_ld + c + 16 * t] = ha[r * LDO + c + 16 * t];
     }
   }
 #pragma unroll
@@ -736,15 +739,21 @@ __device__ __forceinline__ void head_chain_wave(const ClArgs &a, int a0, int na,
           const float xh = (out[t] - mu) * rstd;
           const float y = fmaf(xh, a.chain_ln[i].g[c + 16 * t], a.chain_ln[i].b[c + 16 * t]);
           out[t] = fmaxf(y, 0.f);
-          if constexpr (STASH) {
-            if (i == 0 && r < na) {
+          if constexpr (STASH) {      // (the chain's one LayerNorm: decoder/MLP's hidden layer)
+            if (r < na) {
               st_hxhat[(size_t)r * 32 + c + 16 * t] = xh;
               st_hu[(size_t)r * 32 + c + 16 * t] = out[t];
             }
           }
         }
         if constexpr (STASH) {
-          if (i == 0 && r < na && c == 0) st_hrstd[r] = rstd;
+          if (r < na && c == 0) st_hrstd[r] = rstd;
+        }
+      } else if constexpr (STASH) {
+        if (i == 0 && st_u && r < na) {     // fusion/hist_map's output
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            if (c + 16 * t < n) st_u[(size_t)r * n + c + 16 * t] = out[t];
         }
       }
       alt[r * LDO + c] = out[0];
@@ -1745,7 +1754,8 @@ struct PipeArgs {
 };
 // Layout of the training stash (include/mmt_amd.h, mmt_decoder_stash_layout): one block per layer + a tail block; rows are
 // step-major (row s * B + b), the attention probabilities (B, H, ph, Lk) - the layouts the training kernels read.
-__host__ __device__ __forceinline__ mmt_decoder_stash_layout stash_off(int B, int T, int ph, int d, int dff, int H, int n_out, int nlayers) {
+__host__ __device__ __forceinline__ mmt_decoder_stash_layout stash_off(int B, int T, int ph, int d, int dff, int H, int n_out, int nlayers,
+                                                                       int map_dim = 0) {
   const size_t R = (size_t)ph * B, Rd = R * d;
   mmt_decoder_stash_layout o;
   o.x = 0, o.qkv = Rd, o.a1 = 4 * Rd, o.xhat1 = 5 * Rd, o.x1 = 6 * Rd, o.cq = 7 * Rd, o.a2 = 8 * Rd, o.xhat2 = 9 * Rd, o.x2 = 10 * Rd;
@@ -1754,7 +1764,9 @@ __host__ __device__ __forceinline__ mmt_decoder_stash_layout stash_off(int B, in
   o.p1 = o.rstd3 + R, o.p2 = o.p1 + (size_t)B * H * ph * ph;
   o.layer_floats = (o.p2 + (size_t)B * H * ph * T + 63) & ~(size_t)63;
   o.tail = (size_t)nlayers * o.layer_floats;
-  o.t_x = 0, o.t_ho = Rd, o.t_hu = o.t_ho + R * n_out, o.t_hxhat = o.t_hu + R * 32, o.t_hrstd = o.t_hxhat + R * 32;
+  o.ho_ld = (size_t)(n_out + map_dim);
+  o.t_x = 0, o.t_ho = Rd, o.t_hu = o.t_ho + R * o.ho_ld, o.t_hxhat = o.t_hu + R * 32, o.t_u = o.t_hxhat + R * 32;
+  o.t_hrstd = o.t_u + (map_dim > 0 ? R * n_out : 0);
   o.total_floats = o.tail + ((o.t_hrstd + R + 63) & ~(size_t)63);
   return o;
 }
@@ -2035,7 +2047,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   mmt_decoder_stash_layout so = {};
   size_t st_row0 = 0;                 // stash row of the cluster's first agent at this step
   if constexpr (STASH) {
-    so = stash_off(a.B, a.T, a.ph, d, FS * a.H, a.H, a.n_out, nlayers);
+    so = stash_off(a.B, a.T, a.ph, d, FS * a.H, a.H, a.n_out, nlayers, a.has_map_fusion ? a.map_dim : 0);
     st_row0 = (size_t)a.s * a.B + a0;
   }
   const unsigned tag_out = phase_tag(a), tag_in = tag_of_phase((unsigned)a.prof_idx - 1u);
@@ -2312,7 +2324,7 @@ __device__ __forceinline__ void pipe_stage(const PipeArgs &f, int layer, int g0,
         else if (s + 1 < f.a.ph) nx_cluster = replica, nx_step = s + 1;
       }
       float *stl = nullptr;
-      if constexpr (STASH) stl = f.stash + (size_t)layer * stash_off(a.B, a.T, a.ph, a.d, FS * a.H, a.H, a.n_out, f.nlayers).layer_floats;
+      if constexpr (STASH) stl = f.stash + (size_t)layer * stash_off(a.B, a.T, a.ph, a.d, FS * a.H, a.H, a.n_out, f.nlayers, a.has_map_fusion ? a.map_dim : 0).layer_floats;
       if (!pipe_phase<DH, PHASE, NH, D, FS, DROP, STASH>(a, f.x0buf, m, g0, loadx, S, ps, M, pad, kv_ready, nx_step, nx_cluster, s * 4096 + li,
                                                          f.NC <= f.R, last_phase, stl, f.nlayers)) return;
       kv_ready = nx_cluster >= 0;
@@ -2367,7 +2379,7 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
     for (int i = tid - 256; i < 12 * (d >> 2); i += 256)
       *reinterpret_cast<f32x4 *>(S.xs + (4 + i / (d >> 2)) * ldx + 4 * (i % (d >> 2))) = (f32x4){0.f, 0.f, 0.f, 0.f};
   mmt_decoder_stash_layout so = {};
-  if constexpr (STASH) so = stash_off(a.B, a.T, a.ph, d, 64 * a.H, a.H, a.n_out, f.nlayers);
+  if constexpr (STASH) so = stash_off(a.B, a.T, a.ph, d, 64 * a.H, a.H, a.n_out, f.nlayers, a.has_map_fusion ? a.map_dim : 0);
 #pragma clang loop unroll(disable)
   for (int s = 0; s < f.a.ph + (STASH ? 1 : 0); ++s) {
     const bool head_only = STASH && s == f.a.ph;
@@ -2432,8 +2444,9 @@ __device__ __forceinline__ void pipe_head(const PipeArgs &f, int replica, int j,
         if (wave_chain && wave_id() == 0) {
           if constexpr (STASH) {
             float *tl = f.stash + so.tail;
-            head_chain_wave<CWK, true>(a, a0, na, S.ha, S.hb, S.tok, posl, cw, tl + so.t_ho + st_row0 * a.n_out, tl + so.t_hu + st_row0 * 32,
-                                       tl + so.t_hxhat + st_row0 * 32, tl + so.t_hrstd + st_row0);
+            head_chain_wave<CWK, true>(a, a0, na, S.ha, S.hb, S.tok, posl, cw, tl + so.t_ho + st_row0 * so.ho_ld, tl + so.t_hu + st_row0 * 32,
+                                       tl + so.t_hxhat + st_row0 * 32, tl + so.t_hrstd + st_row0,
+                                       a.has_map_fusion ? tl + so.t_u + st_row0 * a.n_out : nullptr);
           } else {
             head_chain_wave<CWK>(a, a0, na, S.ha, S.hb, S.tok, posl, cw);
           }
@@ -2855,6 +2868,10 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
         (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
+        (void)hipFuncSetAttribute((const void *)mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(pipe_lds_floats<32>(256) * sizeof(float)));
       }
     }
     ds.attr_mask.fetch_or(fam_bit, std::memory_order_release);
@@ -2932,7 +2949,10 @@ static int launch_phases(const mmt_decoder *dec, ClArgs a, int B, int ph, float 
         f.stash = stash;
         if constexpr (DH == 32 && CPW == 2) {    // the pipeline is built for the shipped geometry (pipe_geom_ok): d = 256, d_ff / H = 64
           const size_t plds = pipe_lds_floats<32>(256) * sizeof(float);
-          if (stash) {                           // (mmt_cluster_decoder_stash_ok: the 32-input chain)
+          if (stash && pipe_wide_chain(dec, false)) {      // (mmt_cluster_decoder_stash_ok: fusion/hist_map's 64-input Linear)
+            if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64, true>), dim3(pg.grid), blk, plds, st, f);
+            else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64, true>), dim3(pg.grid), blk, plds, st, f);
+          } else if (stash) {
             if (drop) hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>), dim3(pg.grid), blk, plds, st, f);
             else hipLaunchKernelGGL((mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 32, true>), dim3(pg.grid), blk, plds, st, f);
           } else if (pipe_wide_chain(dec, a.tgt != nullptr)) {      // a head linear with 33..64 inputs (fusion/hist_map): the instantiation that stages them
@@ -3019,8 +3039,10 @@ static bool one_launch_fits(bool pipe, bool cpw2, int grid, int ncu, int d, bool
                              (size_t)16 * KMAX * (DH + 4)) * sizeof(float);
   int per_cu = 0;
   hipError_t e;
-  if (pipe && stash) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>, CNT, lds)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 32, true>, CNT, lds);
+  if (pipe && stash && wide) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64, true>, CNT, lds)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64, true>, CNT, lds);
+  else if (pipe && stash) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 32, true>, CNT, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 32, true>, CNT, lds);
   else if (pipe && wide) e = drop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true, 64>, CNT, lds)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, false, 64>, CNT, lds);
   else if (pipe && drop) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mmt_dec_pipe4_kernel<32, 2, 256, 64, true>, CNT, lds);
@@ -3072,17 +3094,22 @@ extern "C" int mmt_debug_decoder_stall(int on) {
 }
 
 // The pipeline's STASH instantiation (include/mmt_amd.h: mmt_decoder_forward_stash): static conditions + what the device says now
-bool mmt_cluster_decoder_stash_ok(const mmt_decoder *dec, int B, int T, int ph, bool drop) {
-  if (dec->d_model != 256 || dec->nhead != 8 || dec->d_ff != 512 || dec->n_out != 32 || dec->has_map_fusion) return false;
+bool mmt_cluster_decoder_stash_ok(const mmt_decoder *dec, int map_dim, int B, int T, int ph, bool drop) {
+  if (dec->d_model != 256 || dec->nhead != 8 || dec->d_ff != 512 || dec->n_out != 32) return false;
+  if (dec->has_map_fusion) {      // a single Linear (fusion_hist_map_layer = 1) from cat[output_fc, map feature] (<= 64 wide) to 32
+    if (dec->map_fusion.n_hidden != 0 || map_dim < 1 || dec->n_out + map_dim > 64 || dec->map_fusion.out.k != dec->n_out + map_dim ||
+        dec->map_fusion.out.n != 32 || !pipe_wide_chain(dec, false))
+      return false;
+  } else if (map_dim != 0) return false;
   if (dec->head.n_hidden != 1 || dec->head.hidden[0].n != 32 || dec->head.hidden[0].k != 32 || !dec->head.hidden_ln[0].g) return false;
   if (B < 1 || B > PIPE_MAX_B || T < 1 || T > KMAX || ph < 1 || ph > KMAX) return false;
   const int dev = cur_dev(), ncu = dev_ncu(dev), NC = (B + 3) / 4;
   if (cluster_rows(dec, B) != 4 || !pipe_applies(dec, NC, ncu) || g_dev[dev].fused_disabled.load(std::memory_order_relaxed)) return false;
   const PipeGeom pg = pipe_geom(dec->nlayers, dec->nhead, NC, ncu);
-  return one_launch_fits(true, true, pg.grid, ncu, dec->d_model, drop, false, true);
+  return one_launch_fits(true, true, pg.grid, ncu, dec->d_model, drop, dec->has_map_fusion != 0, true);
 }
-void mmt_cluster_decoder_stash_layout(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out) {
-  *out = stash_off(B, T, ph, dec->d_model, dec->d_ff, dec->nhead, dec->n_out, dec->nlayers);
+void mmt_cluster_decoder_stash_layout(const mmt_decoder *dec, int map_dim, int B, int T, int ph, mmt_decoder_stash_layout *out) {
+  *out = stash_off(B, T, ph, dec->d_model, dec->d_ff, dec->nhead, dec->n_out, dec->nlayers, dec->has_map_fusion ? map_dim : 0);
 }
 
 // Same contract as mmt_decoder_forward (arguments already validated there).
@@ -3236,6 +3263,7 @@ static bool sweep_pipe_static_ok(const mmt_sweep_pipe *a) {
   if (a->d != 256 || a->H != 8 || a->d_ff != 64 * a->H || a->n_out != 32 || a->n_pos != 2) return false;
   if (a->nlayers < 1 || a->nlayers > MMT_MAX_LAYERS || 3 * a->nlayers / 8 + 1 > (int)TAG_MASK + 1) return false;      // tag generations: see pipe_applies
   if (a->T < 1 || a->T > KMAX || a->ph < 1 || a->ph > KMAX || a->B < 1 || a->B > PIPE_MAX_B) return false;
+  if (a->w_fuse ? (!a->h_gu || a->map_dim < 1 || a->gho_ld != a->n_out + a->map_dim || a->gho_ld > 64) : a->gho_ld != a->n_out) return false;
   return true;
 }
 static bool sweep_has_dropout(const mmt_sweep_pipe *a) {

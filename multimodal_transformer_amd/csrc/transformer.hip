@@ -511,8 +511,8 @@ int mmt_cluster_decoder_forward(const mmt_decoder *dec, const float *memory, con
                                 const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim,
                                 const float *tgt, int B, int T, int ph, float *pred_st, float *h_out, float *workspace,
                                 int allow_fused, void *stream, const mmt_decoder_dropout *drop, float *stash);
-bool mmt_cluster_decoder_stash_ok(const mmt_decoder *dec, int B, int T, int ph, bool drop);
-void mmt_cluster_decoder_stash_layout(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out);
+bool mmt_cluster_decoder_stash_ok(const mmt_decoder *dec, int map_dim, int B, int T, int ph, bool drop);
+void mmt_cluster_decoder_stash_layout(const mmt_decoder *dec, int map_dim, int B, int T, int ph, mmt_decoder_stash_layout *out);
 
 static thread_local int g_last_path = MMT_PATH_NONE;
 void mmt_note_decoder_path(int path) { g_last_path = path; }
@@ -648,33 +648,35 @@ extern "C" int mmt_decoder_forward_dropout(const mmt_decoder *dec, const float *
 }
 
 // The training step's decode that also keeps what the backward reads (include/mmt_amd.h).
-static bool stash_static_ok(const mmt_decoder *dec, int B, int T, int ph) {
-  return dec && B > 0 && T > 0 && ph > 0 && mmt_cluster_decoder_supports(dec, 0, true, T, ph) && !dec->has_map_fusion;
+static bool stash_static_ok(const mmt_decoder *dec, int map_dim, int B, int T, int ph) {
+  return dec && B > 0 && T > 0 && ph > 0 && map_dim >= 0 && (map_dim > 0) == (dec->has_map_fusion != 0) &&
+         mmt_cluster_decoder_supports(dec, map_dim, true, T, ph);
 }
-extern "C" int mmt_decoder_stash_supported(const mmt_decoder *dec, int B, int T, int ph, int with_dropout) {
-  if (!stash_static_ok(dec, B, T, ph)) return 0;
+extern "C" int mmt_decoder_stash_supported(const mmt_decoder *dec, int map_dim, int B, int T, int ph, int with_dropout) {
+  if (!stash_static_ok(dec, map_dim, B, T, ph)) return 0;
   const int impl = g_decoder_impl_atomic.load(std::memory_order_relaxed);
   if (impl != MMT_DECODER_AUTO && impl != MMT_DECODER_CLUSTER && impl != MMT_DECODER_CLUSTER_PIPELINE) return 0;
-  return mmt_cluster_decoder_stash_ok(dec, B, T, ph, with_dropout != 0) ? 1 : 0;
+  return mmt_cluster_decoder_stash_ok(dec, map_dim, B, T, ph, with_dropout != 0) ? 1 : 0;
 }
-extern "C" int mmt_decoder_stash_layout_of(const mmt_decoder *dec, int B, int T, int ph, mmt_decoder_stash_layout *out) {
-  if (!out || !stash_static_ok(dec, B, T, ph)) return fail(MMT_EINVAL, "mmt_decoder_stash_layout_of: bad arguments or unsupported geometry");
-  mmt_cluster_decoder_stash_layout(dec, B, T, ph, out);
+extern "C" int mmt_decoder_stash_layout_of(const mmt_decoder *dec, int map_dim, int B, int T, int ph, mmt_decoder_stash_layout *out) {
+  if (!out || !stash_static_ok(dec, map_dim, B, T, ph))
+    return fail(MMT_EINVAL, "mmt_decoder_stash_layout_of: bad arguments or unsupported geometry");
+  mmt_cluster_decoder_stash_layout(dec, map_dim, B, T, ph, out);
   return MMT_OK;
 }
 extern "C" int mmt_decoder_forward_stash(const mmt_decoder *dec, const float *memory, const uint8_t *pad_mask, const float *start_pos,
-                                         const float *mem_feat, int mem_feat_dim, int B, int T, int ph, float *pred_st,
-                                         float *workspace, const mmt_decoder_dropout *drop, float *stash, size_t stash_floats,
-                                         void *stream) {
+                                         const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim, int B, int T,
+                                         int ph, float *pred_st, float *workspace, const mmt_decoder_dropout *drop, float *stash,
+                                         size_t stash_floats, void *stream) {
   if (!stash) return fail(MMT_EINVAL, "mmt_decoder_forward_stash: null stash");
-  if (!mmt_decoder_stash_supported(dec, B, T, ph, drop != nullptr))
+  if (!mmt_decoder_stash_supported(dec, map_dim, B, T, ph, drop != nullptr))
     return fail(MMT_EINVAL, "mmt_decoder_forward_stash: not supported for this decoder / batch / device state (mmt_decoder_stash_supported)");
   mmt_decoder_stash_layout lay;
-  mmt_cluster_decoder_stash_layout(dec, B, T, ph, &lay);
+  mmt_cluster_decoder_stash_layout(dec, map_dim, B, T, ph, &lay);
   if (stash_floats < lay.total_floats)
     return fail(MMT_EINVAL, "mmt_decoder_forward_stash: stash of %zu floats, need %zu", stash_floats, lay.total_floats);
-  return decoder_forward_impl(dec, memory, pad_mask, start_pos, nullptr, 0, mem_feat, mem_feat_dim, nullptr, B, T, ph, pred_st, nullptr,
-                              workspace, stream, drop, stash);
+  return decoder_forward_impl(dec, memory, pad_mask, start_pos, map_feat, map_dim, mem_feat, mem_feat_dim, nullptr, B, T, ph, pred_st,
+                              nullptr, workspace, stream, drop, stash);
 }
 
 // ---- the same decode for callers that cannot allocate (include/mmt_amd.h: mmt_decoder_forward_static) ----------------------

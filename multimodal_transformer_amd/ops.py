@@ -624,18 +624,18 @@ def _dropout_desc(dec, sites, B, T, ph):
     return D
 
 
-def decoder_stash_layout(dec: PackedDecoder, B, T, ph):
+def decoder_stash_layout(dec: PackedDecoder, B, T, ph, map_dim=0):
     """Offsets (floats) of the training stash that ``decoder_forward(..., stash=)`` fills (mmt_decoder_stash_layout), or None where
     the geometry has no stash-keeping decode."""
     lay = _lib.DecoderStashLayout()
-    if _lib.load().mmt_decoder_stash_layout_of(C.byref(dec.desc), B, T, ph, C.byref(lay)) != 0:
+    if _lib.load().mmt_decoder_stash_layout_of(C.byref(dec.desc), map_dim, B, T, ph, C.byref(lay)) != 0:
         return None
     return {n: int(getattr(lay, n)) for n in _lib.DecoderStashLayout.FIELDS}
 
 
-def decoder_stash_supported(dec: PackedDecoder, B, T, ph, with_dropout=False):
+def decoder_stash_supported(dec: PackedDecoder, B, T, ph, with_dropout=False, map_dim=0):
     """Whether the next decode can keep the stash (static geometry AND the device's present state: mmt_decoder_stash_supported)."""
-    return bool(_lib.load().mmt_decoder_stash_supported(C.byref(dec.desc), B, T, ph, int(bool(with_dropout))))
+    return bool(_lib.load().mmt_decoder_stash_supported(C.byref(dec.desc), map_dim, B, T, ph, int(bool(with_dropout))))
 
 
 def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12, map_feat=None, mem_feat=None,
@@ -675,13 +675,14 @@ def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12,
     lib = _lib.load()
     ws = _workspace(lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph), dev)
     if stash is not None:
-        if tgt is not None or want_h or map_feat is not None:
-            raise MmtError("decoder_forward: the stash-keeping decode is autoregressive, without map fusion")
+        if tgt is not None or want_h:
+            raise MmtError("decoder_forward: the stash-keeping decode is autoregressive")
         _chk(stash, "stash", (None,))
         D = _dropout_desc(dec, dropout, B, T, ph) if dropout is not None else None
-        _lib.check(lib.mmt_decoder_forward_stash(C.byref(dec.desc), _ptr(memory), _ptr(pad_mask), _ptr(start_pos), _ptr(mem_feat), mf,
-                                                 B, T, ph, _ptr(pred), _ptr(ws), C.byref(D) if D is not None else None, _ptr(stash),
-                                                 stash.numel(), _stream()), "mmt_decoder_forward_stash")
+        _lib.check(lib.mmt_decoder_forward_stash(C.byref(dec.desc), _ptr(memory), _ptr(pad_mask), _ptr(start_pos), _ptr(map_feat), md,
+                                                 _ptr(mem_feat), mf, B, T, ph, _ptr(pred), _ptr(ws),
+                                                 C.byref(D) if D is not None else None, _ptr(stash), stash.numel(), _stream()),
+                   "mmt_decoder_forward_stash")
         return pred, None
     if dropout is not None:
         if tgt is not None or want_h:

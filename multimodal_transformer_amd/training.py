@@ -660,9 +660,19 @@ class TrainEngine:
             md = self.cnn_tape.n_out
             if self.fuse_tape.k_in != no + md or self.fuse_tape.n_out != self.head_tape.k_in:
                 raise MmtError("fusion/hist_map width does not match output_fc + map encoder")
-            S.hcat = b(ph, B, no + md)
+            if S.dec_stash is not None:     # cat[output_fc, map feature], the fusion's output and the head tape live in the tail block
+                R_, ht = ph * B, self.head_tape
+                if lay["ho_ld"] != no + md or self.fuse_tape.hidden or self.fuse_tape.n_out != no:
+                    raise MmtError("decoder stash layout does not match fusion/hist_map")
+                S.hcat = self._stash_view(None, "t_ho", R_ * (no + md), (ph, B, no + md))
+                S.u = self._stash_view(None, "t_u", R_ * no, (ph, B, no))
+                ht.hu[0] = self._stash_view(None, "t_hu", R_ * 32, (ph, B, 32))
+                ht.hxhat[0] = self._stash_view(None, "t_hxhat", R_ * 32, (ph, B, 32))
+                ht.hrstd[0] = self._stash_view(None, "t_hrstd", R_, (ph, B))
+            else:
+                S.hcat = b(ph, B, no + md)
+                S.u = b(ph, B, self.fuse_tape.n_out)
             S.ho = S.hcat[:, :, :no]                       # output_fc writes straight into its columns of the concatenation
-            S.u = b(ph, B, self.fuse_tape.n_out)
             S.gmap = b(B * (no + md))
             S.gmap_c = b(B, md)
             if self.drop.view.get("map.feature") is not None:
@@ -867,12 +877,21 @@ class TrainEngine:
     def _stash_layout(self):
         """Layout of the decoder stash where the stash-keeping decode exists for this configuration (Basic / lane, autoregressive,
         the shipped widths); None otherwise."""
-        if (self.teacher_forced or self.map_mode or torch.device(self.device).type != "cuda" or len(self.head_tape_shape()) != 1
+        if (self.teacher_forced or torch.device(self.device).type != "cuda" or len(self.head_tape_shape()) != 1
                 or self.head_tape_shape()[0] != 32):
             return None
-        lay = ops.decoder_stash_layout(self._packed_decoder(), self.B, self.T, self.ph)
+        if self.map_mode and hasattr(self.fuse.layer_seq, "lmlp_0"):       # (fusion/hist_map with hidden layers: no stash-keeping decode)
+            return None
+        lay = ops.decoder_stash_layout(self._packed_decoder(), self.B, self.T, self.ph, self._stash_map_dim())
         self.__dict__.pop("_pdec_fresh", None)       # (packed at construction: the first decode re-packs the then-current weights)
         return lay
+
+    def _stash_map_dim(self):
+        """width of the map feature that fusion/hist_map concatenates to output_fc's rows (0: no map)"""
+        if not self.map_mode:
+            return 0
+        first = getattr(self.fuse.layer_seq, "lmlp_0", [self.fuse.layer_seq.out_mlp])[0]
+        return int(first.weight.shape[1]) - self.n_out
 
     def head_tape_shape(self):
         """widths of decoder/MLP's hidden layers"""
@@ -888,7 +907,7 @@ class TrainEngine:
             return False
         if self.drop.active and not self._ar_decode_takes_masks():
             return False
-        return ops.decoder_stash_supported(self._packed_decoder(), self.B, self.T, self.ph, self.drop.active)
+        return ops.decoder_stash_supported(self._packed_decoder(), self.B, self.T, self.ph, self.drop.active, self._stash_map_dim())
 
     def _ar_decode_takes_masks(self):
         """Whether the inference decoder kernels can apply this step's keep masks (mmt_decoder_forward_dropout)."""
@@ -1122,8 +1141,9 @@ class TrainEngine:
         self._sweep_pipe_state = False
         dev = torch.device(self.device)
         self.sweep_pipe_why = "configuration (device / teacher forcing / map mode / dropout / head depth)"
-        if (dev.type != "cuda" or not self.sweep_pipeline or self.teacher_forced or self.map_mode
-                or len(self.head_tape.hidden) != 1):
+        if dev.type != "cuda" or not self.sweep_pipeline or self.teacher_forced or len(self.head_tape.hidden) != 1:
+            return None
+        if self.map_mode and (self.fuse_tape.hidden or self.fuse_tape.k_in > 64):      # fusion/hist_map: a single Linear
             return None
         from . import _lib
         import ctypes as C
@@ -1135,6 +1155,10 @@ class TrainEngine:
             return None
         A = _lib.SweepPipe()
         A.B, A.T, A.ph, A.d, A.H, A.nlayers, A.d_ff, A.n_out, A.n_pos = self.B, self.T, self.ph, d, H, L, self.f_dec, self.n_out, self.n_pos
+        A.gho_ld = self.n_out
+        if self.map_mode:       # gradient at cat[output_fc(x), encoded_map] (fuse_tape.gin), at the fusion's output (head_tape.gin)
+            A.w_fuse, A.h_gu = self.fuse_tape.out.weight.data_ptr(), self.head_tape.gin.data_ptr()
+            A.gho_ld, A.map_dim = self.fuse_tape.k_in, self.fuse_tape.k_in - self.n_out
         lib = _lib.load()
         self.sweep_pipe_why = "geometry (mmt_sweep_pipe_workspace_floats)"
         if not lib.mmt_sweep_pipe_workspace_floats(C.byref(A)):
@@ -1185,7 +1209,7 @@ class TrainEngine:
         A.G, A.gx0, A.w_in = P(S.G), P(S.gx[0]), P(dec.input_fc.weight)
         A.w_hout, A.h_gamma, A.w_h0, A.w_ofc = P(out.weight), P(ln0.weight), P(lin0.weight), ofc[0]
         A.h_hu, A.h_xhat, A.h_rstd = P(ht.hu[0]), P(ht.hxhat[0]), P(ht.hrstd[0])
-        A.h_ghum, A.h_ghz, A.h_gho, A.poison = P(ht.ghum[0]), P(ht.ghz[0]), P(ht.gin), P(self.loss)
+        A.h_ghum, A.h_ghz, A.h_gho, A.poison = P(ht.ghum[0]), P(ht.ghz[0]), P(self.fuse_tape.gin if self.map_mode else ht.gin), P(self.loss)
         if self.drop.get("dec.pe") is not None:
             A.k_pe, A.s_pe = P(self.drop.get("dec.pe")[0]), self.drop.get("dec.pe")[1]
         self.sweep_pipe_why = "mmt_sweep_pipe_supported (device fit / disabled)"

@@ -335,11 +335,33 @@ def test_im2col_col2im_match_unfold_fold(B, C, H, W, kh, kw, stride, nhwc):
         assert rel_err(dg.cpu().numpy(), dc.numpy()) <= 1e-5
 
 
-@pytest.mark.parametrize("tiny", [True, False])
-def test_map_cnn_step_matches_reference(tiny):
+def _stash_flips(model, B, T, ph, *batch):
+    """Hidden units that the pipeline decode's stash and the all-steps pass's put on different sides of their ReLU for this model
+    and batch (helpers.relu_flips; to be called before an optimizer step moves the weights)."""
+    from multimodal_transformer_amd import training
+    pair = []
+    for keep in (False, True):
+        e = training.TrainEngine(model, B, T, ph, dropout=False)
+        e.stash_decode = keep
+        e.set_batch(*batch)
+        e.forward()
+        assert e._stash_decode_ok() == keep
+        pair.append(e)
+    flips = helpers.relu_flips(*pair)
+    assert flips[1] <= 1e-5, flips
+    print("units on different sides of their ReLU in the two stashes:", flips)
+    return flips
+
+
+@pytest.mark.parametrize("tiny,stash_decode", [(True, False), (False, False), (False, True)])
+def test_map_cnn_step_matches_reference(tiny, stash_decode):
     """Map_encoding_CNN training step (CNN map encoder + fusion/hist_map train, own learning rate for the map encoder):
     tiny config element-wise against the reference's autograd, full config (B=128, 100x100 rasters) by gradient norms, the
-    first 256 elements of every gradient and the post-AdamW parameters."""
+    first 256 elements of every gradient and the post-AdamW parameters.  Full config with the stash the pipeline decode wrote
+    (the default): 3 x FULL_TOL, as in test_full_config_step_matches_reference_gradient_norms (observed 1.02e-4 at the far end
+    of the backward chain, the encoder's input_fc) where no hidden unit sits on the other side of its ReLU than in the all-steps
+    stash; where one does (this batch: layer 1), norms to 1e-3 and elements to 1e-2 of the RMS."""
+    tol = FULL_TOL * (3 if stash_decode else 1)
     from multimodal_transformer_amd import training
     dev = _dev()
     z, meta = load_golden("tiny_map_cnn" if tiny else "full_map_cnn")
@@ -348,8 +370,12 @@ def test_map_cnn_step_matches_reference(tiny):
     set_weights(reg.model_dict, tiny, z)
     batch = batch_for("map_cnn", tiny)
     x_st, y_st, maps = (torch.from_numpy(batch[k]).to(dev) for k in ("x_st", "y_st", "map"))
+    flips = _stash_flips(model, B, x_st.shape[1], ph, x_st, y_st, maps) if stash_decode else (0, 0.0)
+    tol_n, tol_e = (tol, tol) if flips[0] == 0 else (1e-3, 1e-2)
     tr = training.Trainer(model, B, x_st.shape[1], ph, use_graph=not tiny)
+    tr.engine.stash_decode = stash_decode
     loss = tr.step(x_st, y_st, maps)
+    assert tr.engine._stash_decode_ok() == stash_decode
     assert abs(float(loss) - float(z["train_loss"])) <= TOL * abs(float(z["train_loss"]))
     want = {k for k, v in meta["grad_norms"].items() if v is not None}
     assert set(tr.engine.grad_by_name) == want
@@ -358,9 +384,9 @@ def test_map_cnn_step_matches_reference(tiny):
             assert rel_err(g.cpu().numpy(), z["grad::" + name]) <= TOL, name
         else:
             wn = meta["grad_norms"][name]
-            assert abs(float(g.double().norm()) - wn) <= FULL_TOL * wn + 1e-9, name
+            assert abs(float(g.double().norm()) - wn) <= tol_n * wn + 1e-9, name
             rms = wn / np.sqrt(g.numel())
-            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= FULL_TOL, name
+            assert rel_err(g.reshape(-1)[:256].cpu().numpy(), z["gradhead::" + name], floor=rms + 1e-30) <= tol_e, name
     for name, mod in reg.model_dict.items():
         for pn, p in mod.named_parameters():
             key = f"{name}.{pn}"
@@ -483,19 +509,7 @@ def test_full_config_step_matches_reference_gradient_norms(stash_decode):
     set_weights(reg.model_dict, False, z)
     batch = batch_for("basic", False)
     x_st, y_st = torch.from_numpy(batch["x_st"]).to(dev), torch.from_numpy(batch["y_st"]).to(dev)
-    flips = (0, 0.0)
-    if stash_decode:      # which units differ between the two stashes (before the optimizer moves the weights)
-        pair = []
-        for keep in (False, True):
-            e = training.TrainEngine(model, B, x_st.shape[1], ph, dropout=False)
-            e.stash_decode = keep
-            e.set_batch(x_st, y_st)
-            e.forward()
-            pair.append(e)
-        flips = helpers.relu_flips(*pair)
-        assert flips[1] <= 1e-5, flips
-        print("units on different sides of their ReLU in the two stashes:", flips)
-        del pair
+    flips = _stash_flips(model, B, x_st.shape[1], ph, x_st, y_st) if stash_decode else (0, 0.0)
     tr = training.Trainer(model, B, x_st.shape[1], ph, use_graph=True)
     tr.engine.stash_decode = stash_decode
     loss = tr.step(x_st, y_st)
@@ -951,6 +965,8 @@ def test_a_sweep_that_gave_up_poisons_the_loss_and_leaves_the_weights_alone():
 def _sweep_buffers(eng):
     S, ht = eng.s, eng.head_tape
     out = {"G": S.G, "gho": ht.gin, "ghz": ht.ghz[0], "ghum": ht.ghum[0]}
+    if eng.map_mode:
+        out["gcat"] = eng.fuse_tape.gin
     for l in range(eng.Ld - 1, -1, -1):
         out.update({f"gx[{l + 1}]": S.gx[l + 1], f"gf2[{l}]": S.gf2m[l], f"gf1[{l}]": S.gf1[l], f"gx2[{l}]": S.gx2[l], f"go2[{l}]": S.go2m[l],
                     f"gcq[{l}]": S.gcq[l], f"gmkv[{l}]": S.gmkv[l], f"gx1[{l}]": S.gx1[l], f"go1[{l}]": S.go1m[l], f"gqkv[{l}]": S.gqkv[l]})
@@ -959,7 +975,7 @@ def _sweep_buffers(eng):
 
 
 @pytest.mark.parametrize("mode,B,dropout", [("basic", 128, False), ("basic", 37, False), ("lane_cnn", 64, False), ("basic", 200, False),
-                                             ("basic", 128, True), ("lane_cnn", 29, True)])
+                                             ("basic", 128, True), ("lane_cnn", 29, True), ("map_cnn", 128, False), ("map_cnn", 50, True)])
 def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B, dropout):
     """The reverse-time sweep as ONE weight-stationary pipeline launch (csrc/decoder_bwd_pipe.cuh) against the
     chain of row-block kernels it replaces: every buffer the deferred weight-gradient GEMMs read, in sweep order (the first one that
@@ -970,7 +986,7 @@ def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B, dropout):
     from multimodal_transformer_amd.synthetic import make_batch
     from multimodal_transformer_amd.weights import apply_recipe
     dev = _dev()
-    b = make_batch(B, 8, 12, seed=11, with_lanes=(mode == "lane_cnn"))
+    b = make_batch(B, 8, 12, seed=11, with_lanes=(mode == "lane_cnn"), with_map=(mode == "map_cnn"))
     t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
     res = []
     for pipe in (False, True):
@@ -986,7 +1002,7 @@ def test_pipeline_sweep_matches_the_launch_per_kernel_sweep(mode, B, dropout):
         eng = training.TrainEngine(model, B, 9, 12, dropout=None if dropout else False, seed=5)
         assert eng.drop.active == dropout
         eng.sweep_pipeline = pipe
-        eng.set_batch(t["x_st"], t["y_st"], lanes=t.get("lanes"))
+        eng.set_batch(t["x_st"], t["y_st"], maps=t.get("map"), lanes=t.get("lanes"))
         loss = float(eng.forward())
         eng.backward()
         torch.cuda.synchronize()
@@ -1016,11 +1032,14 @@ def _forward_stash(eng):
             out[f"{n}[{l}]"] = getattr(S, n)[l]
     out[f"x[{eng.Ld}]"] = S.x[eng.Ld]
     out.update({"ho": S.ho, "hu": ht.hu[0], "hxhat": ht.hxhat[0], "hrstd": ht.hrstd[0]})
+    if eng.map_mode:
+        out.update({"hcat": S.hcat, "u": S.u})
     return {k: v.detach().clone() for k, v in out.items()}
 
 
 @pytest.mark.parametrize("mode,B,dropout", [("basic", 128, False), ("basic", 37, False), ("lane_cnn", 64, False), ("basic", 200, False),
-                                             ("basic", 128, True), ("lane_cnn", 29, True), ("basic", 3, True)])
+                                             ("basic", 128, True), ("lane_cnn", 29, True), ("basic", 3, True), ("map_cnn", 128, False),
+                                             ("map_cnn", 50, True)])
 def test_stash_keeping_decode_matches_the_all_steps_pass(mode, B, dropout):
     """mmt_decoder_forward_stash (the pipeline decode whose stages also write what the backward reads) against the decode + all-steps
     recomputation it replaces: same positions bit for bit (same decode arithmetic), every stash tensor in forward order (the first one
@@ -1031,7 +1050,7 @@ def test_stash_keeping_decode_matches_the_all_steps_pass(mode, B, dropout):
     from multimodal_transformer_amd.synthetic import make_batch
     from multimodal_transformer_amd.weights import apply_recipe
     dev = _dev()
-    b = make_batch(B, 8, 12, seed=13, with_lanes=(mode == "lane_cnn"))
+    b = make_batch(B, 8, 12, seed=13, with_lanes=(mode == "lane_cnn"), with_map=(mode == "map_cnn"))
     t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
     res = []
     for keep in (False, True):
@@ -1048,7 +1067,7 @@ def test_stash_keeping_decode_matches_the_all_steps_pass(mode, B, dropout):
         assert eng.drop.active == dropout
         assert eng.s.dec_stash is not None
         eng.stash_decode = keep
-        eng.set_batch(t["x_st"], t["y_st"], lanes=t.get("lanes"))
+        eng.set_batch(t["x_st"], t["y_st"], maps=t.get("map"), lanes=t.get("lanes"))
         for _ in range(2):      # twice: the second pass overwrites a stash that is already filled (same seed step: same masks)
             eng.seed(7, 0)
             loss = float(eng.forward())
