@@ -272,11 +272,16 @@ def bench_train(model, hp, dev, B, history, ph, rank, world, steps, warmup, grou
     if dropout:
         drop_info = {"transformer_and_pe": float(tr.engine.enc.pos_encoder.dropout.p),
                      "mask_bytes_per_step": int(tr.engine.drop.pool.numel()),
-                     "decode": (f"mmt_decoder_forward_dropout: {_last_decoder_path()}, reading the step's keep masks"
+                     "decode": (f"{_last_decoder_path()}, reading the step's keep masks"
                                 if tr.engine._ar_decode_takes_masks() else
                                 "step by step on the stash kernels (tokens depend on the masks)")}
+    eng = tr.engine
+    forms = {"decode": ("mmt_decoder_forward_stash (pipeline decode that keeps the backward's stash)" if eng._stash_decode_ok()
+                        else "decode + all-steps recomputation of the stash"),
+             "sweep": ("mmt_sweep_pipe_run (one weight-stationary pipeline launch)" if eng._sweep_pipe() is not None
+                       else f"launch-per-kernel sweep ({getattr(eng, 'sweep_pipe_why', '')})")}
     tr.close()      # ordered teardown (graphs, events, the last Work) before anybody destroys the process group
-    return {"metric": "train steps/sec (fwd+bwd+clip+AdamW)", "value": steps / elapsed, "unit": "steps/s",
+    return {"metric": "train steps/sec (fwd+bwd+clip+AdamW)", "forms": forms, "value": steps / elapsed, "unit": "steps/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "per_gpu_batch": B,
             "global_batch": B * world, "agents_per_s": B * world * steps / elapsed,
             "allreduce_ms": ar_ms, "allreduce_bytes": 4 * n_par if world > 1 else 0,

@@ -21,9 +21,15 @@ graph draws fresh masks) into a uint8 pool; the forward GEMM epilogues, the atte
 bytes.  One mask per stash position: the reference re-runs the whole decoder on the growing target with fresh masks for
 every pass (mgcvae.py:432-446); here position j of the KV-cached recurrence keeps its mask for the rest of the decode (the
 distribution of each activation is the same, the correlation between passes is not a parity target).
-With dropout the autoregressive tokens depend on the masks, so the decode runs step by step on the stash kernels instead of
-the inference decoder kernels.  With every probability 0 (or modules in eval mode) the dropout-free graph runs, bit for bit
-the one training parity is defined on.
+With dropout the autoregressive tokens depend on the masks: the decode reads the step's keep bytes (mmt_decoder_forward_dropout /
+_stash), or, where the inference decoder kernels cannot (geometry), runs step by step on the stash kernels.  With every
+probability 0 (or modules in eval mode) the dropout-free graph runs, bit for bit the one training parity is defined on.
+
+Round 3, at the shipped widths and B <= 256: the autoregressive decode keeps the decoder's stash itself
+(``TrainEngine.stash_decode``, mmt_decoder_forward_stash: no second, all-steps forward pass) and the reverse-time sweep is ONE
+weight-stationary pipeline launch (``TrainEngine.sweep_pipeline``, mmt_sweep_pipe_run).  Both fall back by themselves to the
+launch-per-kernel forms below (``_decoder_steps``, ``_sweep``) - other geometries, teacher forcing, B > 256, a device whose
+one-launch kernels have timed out - and the tests compare each with the form it replaces.
 """
 from __future__ import annotations
 
