@@ -342,6 +342,15 @@ def config_report(mode, B, dev, history, ph, steps, group, train_steps=0):
     rep = {"workload": f"{mode} transformer --autoregressive predict, VEHICLE, batch {B}, {history}-step history, {ph}-step horizon",
            "value": B * steps / elapsed, "unit": "agents/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
            "kernels_ms": kt, "kernel_rooflines": kr}
+    if B <= 256:        # the same predict replayed from a HIP graph (model.graph_predict = True: a serving loop's form)
+        try:
+            model.graph_predict = True
+            el, _ = timed(group, fn, steps, 5)
+            rep["graph_replay_ms_per_step"] = el / steps * 1e3
+        except Exception as e:
+            rep["graph_replay_ms_per_step"] = f"{type(e).__name__}: {e}"
+        finally:
+            model.graph_predict = False
     if mode == "map_vit":
         rep["parity"] = "unpinned (vit_pytorch==0.33.2 is neither in the reference tree nor installable offline; checked against the CPU restatement only)"
     if mode == "lane_cnn":

@@ -107,6 +107,8 @@ class MultimodalGenerativeCVAE(object):
             module.to(self.device)
 
     # ------------------------------------------------------------------ forward pieces
+    fork_map_encoder = None
+
     def obtain_encoded_tensors(self, mode, inputs, inputs_st, inputs_lane, map):
         """mgcvae.py:231-308.  Returns the same 7-tuple; the causal mask slot is None because the kernels
         rebuild it, the padding mask is the uint8 (B,T) tensor the encoder kernel derived."""
@@ -114,9 +116,14 @@ class MultimodalGenerativeCVAE(object):
         encoded_map = encoded_lane = None
         side = None
         if hp["map_cnn_encoding"] or hp["map_vit_encoding"]:
-            # The map encoder does not depend on the history encoder, and each of them runs one workgroup per agent (tile): at the
-            # benchmark batch (128 agents, 256 CUs) they fit on the chip side by side.  Fork to a second stream, join before the decode.
-            if map.is_cuda:
+            # The map encoder does not depend on the history encoder: it can run on a second stream beside it, joined before the
+            # decode.  Measured at B = 128 (tools/map_fork_ab.py, round 3): the ViT (0.65 ms, one workgroup per agent) beside the
+            # history encoder saves 0.19 ms per predict inside a replayed graph (1.95 -> 1.75 ms) and costs 0.02 ms in eager mode
+            # (no overlap there); the CNN (0.06 ms) only gets in the way of the split encoder's 256 spin-waiting workgroups, whose
+            # residency check cannot see other streams (1.364 against 1.341 ms in line).  So: fork for the ViT, in line for the CNN
+            # (``fork_map_encoder``: None = that rule, True / False = always / never).
+            fork = self.fork_map_encoder if self.fork_map_encoder is not None else bool(hp["map_vit_encoding"])
+            if map.is_cuda and fork:
                 cur = torch.cuda.current_stream(map.device)
                 side = self.__dict__.get("_side_stream") or torch.cuda.Stream(map.device)
                 self.__dict__["_side_stream"] = side

@@ -955,7 +955,8 @@ class TrainEngine:
     def _wgrad_rows(self, dY, X, gw, gb):
         R, M = dY.shape
         N = X.shape[1]
-        if R >= 512 and M % 4 == 0 and N % 4 == 0 and M >= 32 and N >= 32 and dY.stride(1) == 1 and X.stride(1) == 1:
+        if (R >= 512 and R % 4 == 0 and M % 4 == 0 and N % 4 == 0 and M >= 32 and N >= 32 and dY.stride(1) == 1
+                and X.stride(1) == 1):      # (the split-K / group kernels walk K = the rows four at a time)
             # one pass: K range split over SPLITK workgroup slices, bias gradient from the same operand tiles
             sk = self.GROUP_SPLITK if self._deferred is not None else self.SPLITK
             kw = dict(A=dY.t(), B=X, Cm=gw, splitk=sk, part_stride=self.grad_total, asum=gb)

@@ -1113,3 +1113,51 @@ def test_stash_keeping_decode_matches_the_all_steps_pass(mode, B, dropout):
     print("units on different sides of their ReLU:", nflip, "largest activation among them", vflip)
     print("stash-keeping decode vs all-steps pass: worst relative error of a stash tensor", worst, "of a gradient: L2", worst_l2,
           "element-wise", worst_g)
+
+
+@pytest.mark.parametrize("nlayers,B,hist,ph,dropout", [(6, 21, 4, 7, False), (2, 9, 15, 16, True), (3, 130, 8, 1, False), (6, 127, 8, 12, False)])
+def test_training_pipelines_on_other_shapes(nlayers, B, hist, ph, dropout):
+    """Stash-keeping decode + sweep pipeline away from the benchmark shape: short and long histories / horizons (T = 5, 16; ph = 7,
+    16, 1), other depths, ragged cluster counts, row counts that are not a multiple of 4 (the grouped weight-gradient launches then
+    step aside) - against the recomputed stash and the launch-per-kernel sweep on the same masks."""
+    from multimodal_transformer_amd import ops, training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.model import ModelRegistrar, MultimodalGenerativeCVAE
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _dev()
+    b = make_batch(B, hist, ph, seed=17)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    res = []
+    for new_forms in (False, True):
+        hp = make_hyperparams("basic", history=hist, horizon=ph,
+                              transformer={"nlayers": nlayers, "nhead": 8, "in_dim": 256, "fdim": 512, "output_size": 32})
+        hp["autoregressive"] = True
+        reg = ModelRegistrar("/tmp", dev)
+        model = MultimodalGenerativeCVAE(_Env(), "VEHICLE", reg, hp, dev, [])
+        if not dropout:
+            helpers.no_dropout(model)
+        apply_recipe(reg.model_dict, seed=8)
+        eng = training.TrainEngine(model, B, hist + 1, ph, dropout=None if dropout else False, seed=9)
+        assert eng.drop.active == dropout
+        eng.stash_decode = eng.sweep_pipeline = new_forms
+        eng.set_batch(t["x_st"], t["y_st"])
+        loss = float(eng.forward())
+        assert eng._stash_decode_ok() == new_forms
+        fwd = _forward_stash(eng)
+        eng.backward()
+        torch.cuda.synchronize()
+        ops.decoder_status()
+        assert (eng._sweep_pipe() is not None) == new_forms, eng.sweep_pipe_why
+        res.append((loss, fwd, {k: v.clone() for k, v in eng.grad_by_name.items()}))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1]["pos"], res[1][1]["pos"])
+    nflip = 0
+    for name in res[0][1]:
+        a, b_ = res[0][1][name], res[1][1][name]
+        assert rel_err(b_.cpu().numpy(), a.cpu().numpy()) <= 1e-4, name
+        if name.startswith("f1[") or name == "hu":
+            nflip += int(((a > 0) != (b_ > 0)).sum())
+    for name, g in res[1][2].items():
+        got, want = g.double().cpu().numpy(), res[0][2][name].double().cpu().numpy()
+        l2 = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
+        assert l2 <= (1e-4 if nflip == 0 else 5e-3), (name, l2, nflip)
