@@ -624,6 +624,10 @@ def _dropout_desc(dec, sites, B, T, ph):
     return D
 
 
+def decoder_workspace_floats(dec: PackedDecoder, B, T, ph):
+    return int(_lib.load().mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph))
+
+
 def decoder_stash_layout(dec: PackedDecoder, B, T, ph, map_dim=0):
     """Offsets (floats) of the training stash that ``decoder_forward(..., stash=)`` fills (mmt_decoder_stash_layout), or None where
     the geometry has no stash-keeping decode."""
@@ -639,12 +643,14 @@ def decoder_stash_supported(dec: PackedDecoder, B, T, ph, with_dropout=False, ma
 
 
 def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12, map_feat=None, mem_feat=None,
-                    tgt=None, want_h=False, pred_out=None, dropout=None, stash=None):
+                    tgt=None, want_h=False, pred_out=None, dropout=None, stash=None, workspace=None):
     """Autoregressive (tgt=None) or teacher-forced decode.  Returns (pred_st (B,ph,n_in) | None, h (B,ph,n_out) | None).
     ``pred_out``: caller-owned (B,ph,n_in) buffer for the autoregressive result (no allocation in this call).
     ``dropout``: {site: (keep, scale) | None} -- the training step's decode with its keep masks (autoregressive only).
     ``stash``: flat float32 buffer laid out as ``decoder_stash_layout`` says -- the decode also keeps what the backward reads
-    (mmt_decoder_forward_stash; autoregressive only, raises where ``decoder_stash_supported`` is False)."""
+    (mmt_decoder_forward_stash; autoregressive only, raises where ``decoder_stash_supported`` is False).
+    ``workspace``: caller-owned buffer of >= ``decoder_workspace_floats`` floats instead of the per-stream cached one (its first
+    nlayers * B * T * 2 * d_model floats receive the cross-attention K/V of every layer, [layer][b * T + t][k | v])."""
     _chk(memory, "memory", (None, None, dec.d_model))
     B, T, _ = memory.shape
     if pad_mask is not None:
@@ -673,7 +679,14 @@ def decoder_forward(dec: PackedDecoder, memory, pad_mask, start_pos=None, ph=12,
             pred = torch.empty(B, ph, dec.n_in, dtype=torch.float32, device=dev)
     h = torch.empty(B, ph, dec.n_out, dtype=torch.float32, device=dev) if (want_h or tgt is not None) else None
     lib = _lib.load()
-    ws = _workspace(lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph), dev)
+    need = lib.mmt_decoder_workspace_floats(C.byref(dec.desc), B, T, ph)
+    if workspace is not None:
+        _chk(workspace, "workspace", (None,))
+        if workspace.numel() < need:
+            raise MmtError(f"decoder_forward: workspace of {workspace.numel()} floats, need {need}")
+        ws = workspace
+    else:
+        ws = _workspace(need, dev)
     if stash is not None:
         if tgt is not None or want_h:
             raise MmtError("decoder_forward: the stash-keeping decode is autoregressive")

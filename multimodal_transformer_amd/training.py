@@ -34,6 +34,7 @@ one-launch kernels have timed out - and the tests compare each with the form it 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -652,7 +653,16 @@ class TrainEngine:
             for n in ("rstd1", "rstd2", "rstd3"):
                 setattr(S, n, [b(ph, B) for _ in range(L)])
             S.f1 = [b(ph, B, fd) for _ in range(L)]
-        S.mkv = [b(Re, 2 * d) for _ in range(L)]
+        # Cross-attention K/V of the memory, per layer.  The decoder kernels compute them in their prologue, into the head of their
+        # workspace ([layer][b*T + t][k | v]): with an engine-owned workspace the stash IS that region (six GEMMs less per step);
+        # the paths that do not run those kernels (teacher forcing, the step-by-step decode) fill the same views by GEMM.
+        self._dec_ws = None
+        if not self.teacher_forced and torch.device(self.device).type == "cuda":
+            self._dec_ws = b(ops.decoder_workspace_floats(self._packed_decoder(), B, T, ph) + 64)
+            self.__dict__.pop("_pdec_fresh", None)
+            S.mkv = [self._dec_ws[l * Re * 2 * d:(l + 1) * Re * 2 * d].view(Re, 2 * d) for l in range(L)]
+        else:
+            S.mkv = [b(Re, 2 * d) for _ in range(L)]
         S.tmp = b(ph * B, d)
         no = self.n_out
         self.head_tape = _MlpTape(self, self.head, ph, B)
@@ -752,6 +762,7 @@ class TrainEngine:
         D = self.drop.get
         if self.drop.active:
             self.drop.generate()
+        self._prepack()
         K.history_prepare(self.x_st, S.x0, S.pad)
         K.gemm(S.x0, _t(enc.input_fc.weight), S.eh[0], bias=enc.input_fc.bias, addend=S.pe_enc, drop=D("enc.pe"),
                drop_after_add=True)
@@ -776,9 +787,13 @@ class TrainEngine:
             self.memfuse_tape.forward_out(self.memfuse_tape.forward_hidden(S.memcat), S.memf)
             memory = S.memf
         layers = dec.transformer_decoder.layers
-        for l, lay in enumerate(layers):
-            ca = lay.multihead_attn
-            K.gemm(memory, _t(ca.in_proj_weight[d:]), S.mkv[l], bias=ca.in_proj_bias[d:])
+        # (the decoder kernels leave the memory's K/V in S.mkv themselves: see _alloc)
+        kernels_decode = self._dec_ws is not None and not self.teacher_forced and \
+            not (self.drop.active and not self._ar_decode_takes_masks())
+        if not kernels_decode:
+            for l, lay in enumerate(layers):
+                ca = lay.multihead_attn
+                K.gemm(memory, _t(ca.in_proj_weight[d:]), S.mkv[l], bias=ca.in_proj_bias[d:])
         if self.teacher_forced:     # tgt = cat[0, labels_st[:, :-1]], positions start from 0 (mgcvae.py:334-335,370)
             S.pos[0].zero_()
             S.tok[0].zero_()
@@ -794,6 +809,7 @@ class TrainEngine:
                 S.enc_map_d.copy_(S.enc_map)
                 K.dropout_apply(S.enc_map_d, dm[0], dm[1], S.enc_map_d)
                 S.enc_map_used = S.enc_map_d
+        self._join_packs()
         if self.teacher_forced:     # positions = running sum of the head outputs (mgcvae.py:352,370), from pos[0] = 0
             self._decoder_steps(0, ph)
             R = ph * B
@@ -915,6 +931,38 @@ class TrainEngine:
             return False
         return ops.decoder_stash_supported(self._packed_decoder(), self.B, self.T, self.ph, self.drop.active, self._stash_map_dim())
 
+    # Measured in graph replay at B = 128: 3.44 ms per step with the packs forked to a second stream, 3.37 in line - a fork / join
+    # inside a replayed HIP graph costs more (~35 us each way) than the two launches it hides (42 us).  Off.
+    prepack = os.environ.get("MMT_PREPACK") is not None
+
+    def _prepack(self):
+        """The 4x4x1-order copies of the decoder's weights (forward pipeline) and their transposes (sweep pipeline) follow the
+        parameters: re-laid out once per step.  Nothing before the decode reads them, so the two launches go to a second stream
+        beside the history encoder's forward (a chain of small kernels that leaves most of the chip idle); ``_ar_decode`` joins."""
+        self._packs_stream = None
+        if not self.prepack or torch.device(self.device).type != "cuda" or self.teacher_forced or self._pdec is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        side = self.__dict__.get("_pack_stream")
+        if side is None:
+            side = self._pack_stream = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if not self.__dict__.pop("_pdec_fresh", False):
+                self._pdec.repack()
+            self._pdec_packed = True
+            sp = self.__dict__.get("_sweep_pipe_state")
+            if sp:
+                sp[1].run()
+                self._sweep_packed = True
+        self._packs_stream = side
+
+    def _join_packs(self):
+        side = self.__dict__.get("_packs_stream")
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._packs_stream = None
+
     def _ar_decode_takes_masks(self):
         """Whether the inference decoder kernels can apply this step's keep masks (mmt_decoder_forward_dropout)."""
         ok = self.__dict__.get("_ar_masks_ok")
@@ -934,6 +982,8 @@ class TrainEngine:
             self._pdec = ops.PackedDecoder(dev_sd(self.dec), self.H, dev_sd(self.head),
                                            dev_sd(self.fuse) if self.map_mode else None,
                                            dev_sd(self.memfuse) if self.lane_mode else None)
+        elif self.__dict__.pop("_pdec_packed", False):
+            self._join_packs()      # (re-laid out beside the encoder's forward: _prepack)
         elif self.__dict__.pop("_pdec_fresh", False):
             pass                    # (built by _packed_decoder in this very step)
         else:
@@ -944,7 +994,7 @@ class TrainEngine:
         ops.decoder_forward(self._pdec, S.eh[self.Le].view(self.B, self.T, self.d), S.pad, start_pos=S.pos[0], ph=self.ph,
                             map_feat=S.enc_map_used if self.map_mode else None,
                             mem_feat=S.enc_lane[:, 0, :].contiguous() if self.lane_mode else None, pred_out=S.pred, dropout=sites,
-                            stash=S.dec_stash if stash else None)
+                            stash=S.dec_stash if stash else None, workspace=self._dec_ws)
         S.pos[1:].copy_(S.pred.permute(1, 0, 2))
 
     # ------------------------------------------------------------------ backward
@@ -1237,7 +1287,9 @@ class TrainEngine:
         A, pk, ws = sp
         if not _lib.load().mmt_sweep_pipe_supported(C.byref(A)):      # e.g. the one-launch forms were disabled after a time-out
             return False
-        pk.run()                                   # the transposed weight packs follow the parameters (one launch)
+        self._join_packs()
+        if not self.__dict__.pop("_sweep_packed", False):
+            pk.run()                               # the transposed weight packs follow the parameters (one launch; else: _prepack)
         _lib.check(_lib.load().mmt_sweep_pipe_run(C.byref(A), C.c_void_p(ws.data_ptr()), ops._stream()), "mmt_sweep_pipe_run")
         return True
 
