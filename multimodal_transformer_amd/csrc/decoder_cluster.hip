@@ -1806,6 +1806,16 @@ __device__ __forceinline__ PipeLds pipe_lds(float *smem, int d) {
 #ifndef FW_PROBES
 #define FW_PROBES 1
 #endif
+// (timing experiments: which of the stash-keeping decode's stores cost what - all on in every shipped build)
+#ifndef STASH_RED
+#define STASH_RED 1
+#endif
+#ifndef STASH_T1
+#define STASH_T1 1
+#endif
+#ifndef STASH_ATT
+#define STASH_ATT 1
+#endif
 #ifndef FW_PROBE_SLOT0
 #define FW_PROBE_SLOT0 1        // probe the part of slice 0 (that workgroup also writes the residual row): 1.049 -> 1.044 ms at B = 128
 #endif
@@ -2122,23 +2132,20 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   if (red_wave) {
     // STASH: the slice-0 workgroup keeps the sub-layer's input row (x / x1 / x2) and the LayerNorm that made it (self-attention
     // stage: the PREVIOUS layer's norm3)
+    // (parked in rows 4..8 of the input tile, which only the head workgroups use, and written out behind the visit's hand-off:
+    // stash_flush below - a global store ahead of the hand-off costs 0.2 us per hop)
     float *st_x = nullptr, *st_xhat = nullptr, *st_rstd = nullptr;
-    if constexpr (STASH) {
+    if constexpr (STASH && STASH_RED != 0) {
       if (g0 == 0 && wave_id() < na) {
-        const size_t row = st_row0 + wave_id();
-        st_x = stl + (PHASE == PH_A ? so.x : PHASE == PH_B ? so.x1 : so.x2) + row * d;
-        float *lnl = PHASE == PH_A ? stl - so.layer_floats : stl;
-        st_xhat = lnl + (PHASE == PH_A ? so.xhat3 : PHASE == PH_B ? so.xhat1 : so.xhat2) + row * d;
-        st_rstd = lnl + (PHASE == PH_A ? so.rstd3 : PHASE == PH_B ? so.rstd1 : so.rstd2) + row;
+        st_x = S.xs + (12 + wave_id()) * ldx;          // (reduce4_finish also writes the row to xs itself: this copy is not read)
+        st_xhat = S.xs + (4 + wave_id()) * ldx;
+        st_rstd = S.xs + 8 * ldx + wave_id();
       }
     }
     if (loadx) {
       if (lane_id() < (d >> 2)) {
         *reinterpret_cast<f32x4 *>(S.xs + wave_id() * ldx + 4 * lane_id()) = R.res;
         if (g0 == 0) bs4x<AUX>(mk_rsrc(a.xres_out + ((size_t)cluster * 16 + wave_id()) * d), (unsigned)lane_id() * 16u, tag4(R.res, tag_out));
-        if constexpr (STASH) {
-          if (st_x) *reinterpret_cast<f32x4 *>(st_x + 4 * lane_id()) = R.res;
-        }
       }
     } else {
       reduce4_finish<AUX, DROP, false, STASH>(R, a, cluster, S.xs, ldx, g0 == 0, true, DROP ? &k_red : nullptr, st_x, st_xhat, st_rstd);
@@ -2168,7 +2175,7 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
   PSTAMP(visit, 7);
   __syncthreads();
   PSTAMP(visit, 3);
-  if constexpr (STASH) {      // the first linear's result (q|k|v of the head, the heads' cross queries, the hidden slice): waves 2, 3
+  if constexpr (STASH && STASH_T1 != 0) {      // the first linear's result (q|k|v of the head, the heads' cross queries, the hidden slice): waves 2, 3
     constexpr int C4 = DH / 4;
     const int i = tid - 128;
     if constexpr (PHASE == PH_A) {
@@ -2194,20 +2201,31 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
       }
     }
   }
+  // stash: row w of the sub-layer's input (and its LayerNorm's normalised row, 1/std, parked in rows 4..8 of the input tile) goes
+  // out on wave `wv` - a wave that idles through the attention (A, B), or the row's own red wave behind the hand-off (C)
+  auto stash_rows = [&](int w, int q) {
+    if (g0 != 0 || w >= na || q >= (d >> 2)) return;
+    const size_t row = st_row0 + w;
+    *reinterpret_cast<f32x4 *>(stl + (PHASE == PH_A ? so.x : PHASE == PH_B ? so.x1 : so.x2) + row * d + 4 * q) =
+        *reinterpret_cast<const f32x4 *>(S.xs + w * ldx + 4 * q);
+    if (!loadx) {
+      float *lnl = PHASE == PH_A ? stl - so.layer_floats : stl;
+      *reinterpret_cast<f32x4 *>(lnl + (PHASE == PH_A ? so.xhat3 : PHASE == PH_B ? so.xhat1 : so.xhat2) + row * d + 4 * q) =
+          *reinterpret_cast<const f32x4 *>(S.xs + (4 + w) * ldx + 4 * q);
+      if (q == 0) lnl[(PHASE == PH_A ? so.rstd3 : PHASE == PH_B ? so.rstd1 : so.rstd2) + row] = S.xs[8 * ldx + w];
+    }
+  };
   // ---- 4. attention: wave h serves head g0 + h
   if constexpr (PHASE != PH_C) {
+    if constexpr (STASH && STASH_RED != 0) {
+      if (wave_id() >= 4) stash_rows(wave_id() - 4, lane_id());      // (xs is not written again before the next visit's poll)
+    }
     if (wave_id() < NH) {
       const int h = wave_id();
-      float *st_p = nullptr, *st_o = nullptr;
-      size_t st_ps = 0;
-      if constexpr (STASH) {
-        const int Lk = PHASE == PH_A ? a.ph : a.T;
-        st_ps = (size_t)a.H * a.ph * Lk;
-        st_p = stl + (PHASE == PH_A ? so.p1 : so.p2) + (((size_t)a0 * a.H + g0 + h) * a.ph + a.s) * Lk;
-        st_o = stl + (PHASE == PH_A ? so.a1 : so.a2) + st_row0 * d + (g0 + h) * DH;
-      }
+      float *st_p = nullptr;      // the softmax before its dropout: parked in row 9 of the input tile (16 keys per agent), see stash_flush
+      if constexpr (STASH && STASH_ATT != 0) st_p = S.xs + 9 * ldx + h * 64;
       attend4<DH, PHASE, PIPE_ATT_ZEROED>(a, na, pad_now, S.t1 + h * 4 * LD1, LD1, S.Ks + h * 4 * KMAX * LDK, S.Vs + h * 4 * KMAX * LDK, S.ps + h * 64,
-                         S.ob + h * 4 * LDO, visit, (DROP && on_att) ? (int)(kb_att & 0xffu) : -1, st_p, st_ps, st_o);
+                         S.ob + h * 4 * LDO, visit, (DROP && on_att) ? (int)(kb_att & 0xffu) : -1, st_p, 16, nullptr);
     } else if (PHASE == PH_A && tid >= 256) {        // meanwhile: the new key / value into the cache (read back by this workgroup only)
       const int i = tid - 256;
       if (i < na * 2 * (DH / 4)) {
@@ -2243,6 +2261,29 @@ __device__ __forceinline__ bool pipe_phase(const ClArgs &a, const float *x0buf, 
       gemm2_4s<DH, PHASE, D, FS, AUX>(M[h], PHASE == PH_C ? S.t1 : S.ob + h * 4 * LDO, PHASE == PH_C ? LD1 : LDO, part_of(g0 + h), tag_out, ldp);
   }
   PSTAMP(visit, 5);
+  if constexpr (STASH) {
+    // stash_flush: what was parked in LDS goes to the stash now, behind the hand-off.  Every wave writes out what it parked itself
+    // (and will overwrite itself at the next visit), so no barrier is needed.
+    if constexpr (PHASE == PH_C && STASH_RED != 0) {
+      if (wave_id() < 4) stash_rows(wave_id(), lane_id());      // (the row's own red wave: it is the one that rewrites the row)
+    }
+    // softmax rows and attention outputs: on waves 4.., which have nothing to do until the next visit's first barrier (and reach
+    // that barrier only behind these reads, so the next attention cannot overwrite the tiles under them)
+    if constexpr (PHASE != PH_C && STASH_ATT != 0) {
+      if (wave_id() >= 4 && wave_id() < 4 + NH) {
+        const int h = wave_id() - 4, lane = lane_id(), ar = lane >> 4, l16 = lane & 15, Lk = PHASE == PH_A ? a.ph : a.T;
+        const int nkeys = PHASE == PH_A ? a.s + 1 : a.T;
+        if (ar < na) {
+          if (l16 < nkeys)
+            stl[(PHASE == PH_A ? so.p1 : so.p2) + ((((size_t)a0 + ar) * a.H + g0 + h) * a.ph + a.s) * Lk + l16] = S.xs[9 * ldx + h * 64 + lane];
+          constexpr int DPL = DH / 16;
+          typedef float vrow __attribute__((ext_vector_type(DPL)));
+          *reinterpret_cast<vrow *>(stl + (PHASE == PH_A ? so.a1 : so.a2) + (st_row0 + ar) * d + (g0 + h) * DH + l16 * DPL) =
+              *reinterpret_cast<const vrow *>(S.ob + (h * 4 + ar) * LDO + l16 * DPL);
+        }
+      }
+    }
+  }
   PSTAMP(visit, 6);
   PSTAMPC(visit, 13);
   return true;
