@@ -117,8 +117,13 @@ def test_group_launch_planner_validates_jobs_and_lays_out_the_table():
     assert bytes(buf[:2 * ctypes.sizeof(_lib.GemmArgs)]) == bytes(jobs)
     blocks = (ctypes.c_int32 * (4 * nblocks.value)).from_buffer_copy(bytes(buf[2 * ctypes.sizeof(_lib.GemmArgs):]))
     rows = [tuple(blocks[4 * i:4 * i + 4]) for i in range(nblocks.value)]
-    assert rows[0] == (0, 0, 0, 0) and rows[-1] == (1, 0, 1, 3) and len(set(rows)) == len(rows)
-    assert sum(1 for r in rows if r[0] == 0) == 24
+    # every tile exactly once; the jobs are dealt over 8 lanes (table entry 8 i + x = i-th tile of lane x: workgroups go round-robin
+    # over the 8 XCDs, so a job's tiles share one L2) - here job 0 on lane 0, job 1 on lane 1, until job 1 runs out
+    assert len(set(rows)) == len(rows) and sum(1 for r in rows if r[0] == 0) == 24
+    assert set(rows) == {(0, x, y, z) for x in range(3) for y in range(2) for z in range(4)} | \
+        {(1, 0, y, z) for y in range(2) for z in range(4)}
+    assert rows[0] == (0, 0, 0, 0) and rows[1] == (1, 0, 0, 0) and [r[0] for r in rows[:16]] == [0, 1] * 8
+    assert all(r[0] == 0 for r in rows[16:])
     jobs[1].relu = 1                                            # an epilogue: not a split-K weight-gradient job
     assert lib.mmt_gemm_group_plan(jobs, 2, None, 0, ctypes.byref(nbytes), ctypes.byref(nblocks)) != 0
     assert b"job 1" in lib.mmt_last_error()
