@@ -668,7 +668,7 @@ extern "C" int mmt_decoder_forward_stash(const mmt_decoder *dec, const float *me
                                          const float *map_feat, int map_dim, const float *mem_feat, int mem_feat_dim, int B, int T,
                                          int ph, float *pred_st, float *workspace, const mmt_decoder_dropout *drop, float *stash,
                                          size_t stash_floats, void *stream) {
-  if (!stash) return fail(MMT_EINVAL, "mmt_decoder_forward_stash: null stash");
+  if (!stash || ((uintptr_t)stash & 15)) return fail(MMT_EINVAL, "mmt_decoder_forward_stash: stash must be a 16-byte aligned device buffer");
   if (!mmt_decoder_stash_supported(dec, map_dim, B, T, ph, drop != nullptr))
     return fail(MMT_EINVAL, "mmt_decoder_forward_stash: not supported for this decoder / batch / device state (mmt_decoder_stash_supported)");
   mmt_decoder_stash_layout lay;
