@@ -657,7 +657,7 @@ class TrainEngine:
         # workspace ([layer][b*T + t][k | v]): with an engine-owned workspace the stash IS that region (six GEMMs less per step);
         # the paths that do not run those kernels (teacher forcing, the step-by-step decode) fill the same views by GEMM.
         self._dec_ws = None
-        if not self.teacher_forced and torch.device(self.device).type == "cuda":
+        if self.alias_memory_kv and not self.teacher_forced and torch.device(self.device).type == "cuda":
             self._dec_ws = b(ops.decoder_workspace_floats(self._packed_decoder(), B, T, ph) + 64)
             self.__dict__.pop("_pdec_fresh", None)
             S.mkv = [self._dec_ws[l * Re * 2 * d:(l + 1) * Re * 2 * d].view(Re, 2 * d) for l in range(L)]
@@ -894,6 +894,7 @@ class TrainEngine:
             self._pdec_fresh = True
         return self._pdec
 
+    alias_memory_kv = True   # the memory's K/V stash = the decoder kernels' own prologue output (False: six GEMMs, tests)
     stash_decode = True      # let the pipeline decode keep the backward's stash (False: always the all-steps pass)
 
     def _stash_layout(self):

@@ -1161,3 +1161,39 @@ def test_training_pipelines_on_other_shapes(nlayers, B, hist, ph, dropout):
         got, want = g.double().cpu().numpy(), res[0][2][name].double().cpu().numpy()
         l2 = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30))
         assert l2 <= (1e-4 if nflip == 0 else 5e-3), (name, l2, nflip)
+
+
+@pytest.mark.parametrize("mode,B,ph", [("basic", 12, 20), ("lane_cnn", 300, 12), ("basic", 24, 12)])
+def test_memory_kv_taken_from_the_decoder_kernels_equals_the_gemm(monkeypatch, mode, B, ph):
+    """The training stash of the memory's cross-attention K/V is the head of the decoder kernels' workspace (their own prologue
+    output) instead of six GEMMs - for every kernel family the decode may run on: the persistent kernel (horizon 20), the 16-row
+    launch-per-phase kernels (300 agents, with the lane configuration's fused memory) and the pipeline.  Against an engine that
+    computes them by GEMM: the K/V themselves to rounding, loss equal, gradients to 1e-4 (whole tensor)."""
+    from multimodal_transformer_amd import training
+    from multimodal_transformer_amd.config import make_hyperparams
+    from multimodal_transformer_amd.synthetic import make_batch
+    from multimodal_transformer_amd.weights import apply_recipe
+    dev = _dev()
+    b = make_batch(B, 8, ph, seed=23, with_lanes=(mode == "lane_cnn"))
+    t = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    res = []
+    for alias in (False, True):
+        monkeypatch.setattr(training.TrainEngine, "alias_memory_kv", alias)
+        hp = make_hyperparams(mode, history=8, horizon=ph)
+        model, reg = _model(hp, dev)
+        apply_recipe(reg.model_dict, seed=3)
+        eng = training.TrainEngine(model, B, 9, ph, dropout=False)
+        assert (eng._dec_ws is not None) == alias
+        eng.stash_decode = False            # both read the all-steps pass's stash: only the K/V differ
+        eng.set_batch(t["x_st"], t["y_st"], lanes=t.get("lanes"))
+        loss = float(eng.forward())
+        mkv = [m.clone() for m in eng.s.mkv]
+        eng.backward()
+        torch.cuda.synchronize()
+        res.append((loss, mkv, {k: v.clone() for k, v in eng.grad_by_name.items()}))
+    assert res[0][0] == res[1][0]
+    for a, b_ in zip(res[0][1], res[1][1]):
+        assert rel_err(b_.cpu().numpy(), a.cpu().numpy()) <= 1e-5
+    for name, g in res[1][2].items():
+        got, want = g.double().cpu().numpy(), res[0][2][name].double().cpu().numpy()
+        assert float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)) <= 1e-4, name
